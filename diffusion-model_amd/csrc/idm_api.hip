@@ -1,0 +1,436 @@
+// C-ABI of libisingdiff.so (declared in include/isingdiff.h): model handle, weight repacking,
+// workspace management and the layer schedule of the UNet forward / reverse sampler.
+#include "../../include/isingdiff.h"
+#include "idm_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(IDM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+
+uint16_t bf16_bits(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// Keras kernel (3,3,Cin,Cout) -> bf16 A-fragments of v_mfma_f32_32x32x16_bf16, [tap][c/16][mt][lane][8]:
+// lane l holds W[tap][16*cg + 8*(l>>5) + j][32*mt + (l&31)], j = 0..7.
+std::vector<uint16_t> pack_weights_bf16(const float *w, int cin, int cout)
+{
+    const int ncg = cin / 16, mt = cout / 32;
+    std::vector<uint16_t> p((size_t)9 * cin * cout);
+    size_t o = 0;
+    for (int tap = 0; tap < 9; ++tap)
+        for (int cg = 0; cg < ncg; ++cg)
+            for (int m = 0; m < mt; ++m)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = cg * 16 + 8 * (l >> 5) + j, co = m * 32 + (l & 31);
+                        p[o++] = bf16_bits(w[((size_t)tap * cin + c) * cout + co]);
+                    }
+    return p;
+}
+
+// Keras kernel -> float A operands of v_mfma_f32_32x32x2_f32, [tap][c/8][mt][lane][4]:
+// element s of lane l is W[tap][8*cg + 2*s + (l>>5)][32*mt + (l&31)].
+std::vector<float> pack_weights_f32(const float *w, int cin, int cout)
+{
+    const int ncg = cin / 8, mt = cout / 32;
+    std::vector<float> p((size_t)9 * cin * cout);
+    size_t o = 0;
+    for (int tap = 0; tap < 9; ++tap)
+        for (int cg = 0; cg < ncg; ++cg)
+            for (int m = 0; m < mt; ++m)
+                for (int l = 0; l < 64; ++l)
+                    for (int s = 0; s < 4; ++s) {
+                        const int c = cg * 8 + 2 * s + (l >> 5), co = m * 32 + (l & 31);
+                        p[o++] = w[((size_t)tap * cin + c) * cout + co];
+                    }
+    return p;
+}
+
+}  // namespace
+
+struct idm_model {
+    int device = 0;
+    int C = 1, F = 32;
+    bool bn = false;
+    int cin[IDM_NCONV], cout[IDM_NCONV];
+    float *w_first = nullptr;              // (9, C, F) float32
+    float *w_head = nullptr;               // (F, C) float32
+    void *wpack_f32[IDM_NCONV] = {};       // layers 1..9
+    void *wpack_bf16[IDM_NCONV] = {};
+    float *bias[IDM_NCONV] = {};
+    float *scale[IDM_NCONV] = {};
+    float *shift[IDM_NCONV] = {};
+    float *dense_w[IDM_NDENSE] = {};
+    float *dense_b[IDM_NDENSE] = {};
+    float *ttable = nullptr;
+    int ttable_T = 0;
+    float *trow = nullptr;                 // time-embedding row for an arbitrary t_norm
+    char *ws = nullptr;                    // activation workspace
+    size_t ws_bytes = 0;
+    std::vector<void *> owned;
+};
+
+namespace {
+
+template <typename T>
+int upload(idm_model *m, const T *host, size_t n, T **dev)
+{
+    HIPCHK(hipMalloc((void **)dev, n * sizeof(T)));
+    m->owned.push_back(*dev);
+    HIPCHK(hipMemcpy(*dev, host, n * sizeof(T), hipMemcpyHostToDevice));
+    return IDM_OK;
+}
+
+struct Plan {
+    int H, W, Hp, Wp;
+    size_t es;  // activation element size
+    size_t off_a0, off_s1, off_a2, off_s2, off_a4, off_a5, off_a6, off_a7, off_a8, off_a9, off_score, per_lattice;
+};
+
+Plan make_plan(const idm_model *m, int H, int W, int precision)
+{
+    Plan p;
+    p.H = H; p.W = W;
+    p.Hp = H + (4 - H % 4) % 4;
+    p.Wp = W + (4 - W % 4) % 4;
+    p.es = precision == IDM_BF16 ? 2 : 4;
+    const size_t n1 = (size_t)p.Hp * p.Wp, n2 = n1 / 4, n4 = n1 / 16, F = m->F;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    p.off_a0 = take(n1 * F * p.es);
+    p.off_s1 = take(n1 * F * p.es);
+    p.off_a2 = take(n2 * 2 * F * p.es);
+    p.off_s2 = take(n2 * 2 * F * p.es);
+    p.off_a4 = take(n4 * 4 * F * p.es);
+    p.off_a5 = take(n4 * 4 * F * p.es);
+    p.off_a6 = take(n2 * 2 * F * p.es);
+    p.off_a7 = take(n2 * 2 * F * p.es);
+    p.off_a8 = take(n1 * F * p.es);
+    p.off_a9 = take(n1 * F * 4);
+    p.off_score = take((size_t)H * W * m->C * 4);
+    p.per_lattice = o;
+    return p;
+}
+
+int ensure_ws(idm_model *m, size_t bytes)
+{
+    if (m->ws_bytes >= bytes) return IDM_OK;
+    if (m->ws) { HIPCHK(hipFree(m->ws)); m->ws = nullptr; m->ws_bytes = 0; }
+    hipError_t e = hipMalloc((void **)&m->ws, bytes);
+    if (e != hipSuccess) return fail(IDM_ERR_NOMEM, "workspace allocation of " + std::to_string(bytes) + " bytes failed");
+    m->ws_bytes = bytes;
+    return IDM_OK;
+}
+
+int64_t auto_chunk(const Plan &p, int64_t B)
+{
+    const size_t budget = (size_t)6 << 30;  // keep the activation workspace around 6 GiB
+    int64_t c = (int64_t)std::max<size_t>(1, budget / p.per_lattice);
+    return std::min<int64_t>(B, c);
+}
+
+// Forward for `Bc` lattices whose workspace starts at m->ws.  Buffers of one kind are contiguous
+// over the chunk: base + off_kind*Bc.
+int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd, float *score, int64_t Bc,
+                  int precision, float *const *taps, int64_t tap_b0, hipStream_t s)
+{
+    char *ws = m->ws;
+    auto buf = [&](size_t off) { return (void *)(ws + off * (size_t)Bc); };
+    void *a0 = buf(p.off_a0), *s1 = buf(p.off_s1), *a2 = buf(p.off_a2), *s2 = buf(p.off_s2), *a4 = buf(p.off_a4),
+         *a5 = buf(p.off_a5), *a6 = buf(p.off_a6), *a7 = buf(p.off_a7), *a8 = buf(p.off_a8);
+    float *a9 = (float *)buf(p.off_a9);
+    const bool bf = precision == IDM_BF16;
+    const int F = m->F, Hp = p.Hp, Wp = p.Wp;
+
+    launch_conv_first(x, Bc, p.H, p.W, Hp, Wp, m->C, m->w_first, m->bias[0], m->scale[0], m->shift[0], a0, F, bf, s);
+
+    auto conv = [&](int layer, const void *in0, const void *in1, int C0, int C1, int H, int W, int mode, void *out,
+                    const float *ta, bool out_f32) {
+        ConvArgs a;
+        a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.H = H; a.W = W; a.B = Bc;
+        a.wpack = bf ? m->wpack_bf16[layer] : m->wpack_f32[layer];
+        a.bias = m->bias[layer]; a.scale = m->scale[layer]; a.shift = m->shift[layer]; a.tadd = ta;
+        a.out = out; a.Cout = m->cout[layer]; a.mode = mode; a.silu = 1; a.out_f32 = out_f32 ? 1 : 0;
+        if (bf) launch_conv_bf16(a, s); else launch_conv_f32(a, s);
+    };
+    conv(1, a0, nullptr, F, 0, Hp, Wp, CONV_PLAIN, s1, nullptr, false);
+    conv(2, s1, nullptr, F, 0, Hp / 2, Wp / 2, CONV_POOL, a2, nullptr, false);
+    conv(3, a2, nullptr, 2 * F, 0, Hp / 2, Wp / 2, CONV_PLAIN, s2, nullptr, false);
+    conv(4, s2, nullptr, 2 * F, 0, Hp / 4, Wp / 4, CONV_POOL, a4, tadd, false);
+    conv(5, a4, nullptr, 4 * F, 0, Hp / 4, Wp / 4, CONV_PLAIN, a5, nullptr, false);
+    conv(6, a5, s2, 4 * F, 2 * F, Hp / 2, Wp / 2, CONV_UPCAT, a6, nullptr, false);
+    conv(7, a6, nullptr, 2 * F, 0, Hp / 2, Wp / 2, CONV_PLAIN, a7, nullptr, false);
+    conv(8, a7, s1, 2 * F, F, Hp, Wp, CONV_UPCAT, a8, nullptr, false);
+    conv(9, a8, nullptr, F, 0, Hp, Wp, CONV_PLAIN, a9, nullptr, true);
+    launch_head(a9, Bc, p.H, p.W, Hp, Wp, F, m->C, m->w_head, m->bias[10], score, s);
+
+    if (taps) {
+        const size_t n1 = (size_t)Hp * Wp, n2 = n1 / 4, n4 = n1 / 16;
+        const void *src[10] = {a0, s1, a2, s2, a4, a5, a6, a7, a8, a9};
+        const size_t cnt[10] = {n1 * F, n1 * F, n2 * 2 * F, n2 * 2 * F, n4 * 4 * F, n4 * 4 * F, n2 * 2 * F, n2 * 2 * F, n1 * F, n1 * F};
+        for (int i = 0; i < 10; ++i) {
+            if (!taps[i]) continue;
+            float *dst = taps[i] + (size_t)tap_b0 * cnt[i];
+            if (bf && i != 9) launch_cast_bf16_to_f32(src[i], dst, (int64_t)(cnt[i] * Bc), s);
+            else HIPCHK(hipMemcpyAsync(dst, src[i], cnt[i] * Bc * 4, hipMemcpyDeviceToDevice, s));
+        }
+        if (taps[10]) {
+            if (p.H != Hp || p.W != Wp) return fail(IDM_ERR_UNSUPPORTED, "tap 10 needs H and W to be multiples of 4");
+            HIPCHK(hipMemcpyAsync(taps[10] + (size_t)tap_b0 * p.H * p.W * m->C, score, (size_t)Bc * p.H * p.W * m->C * 4,
+                                  hipMemcpyDeviceToDevice, s));
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return IDM_OK;
+}
+
+int check_shape(const idm_model *m, int64_t B, int H, int W, int precision)
+{
+    if (!m) return fail(IDM_ERR_INVALID, "null model");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(IDM_ERR_INVALID, "B, H and W must be positive");
+    if (precision != IDM_FP32 && precision != IDM_BF16) return fail(IDM_ERR_INVALID, "unknown precision");
+    if ((int64_t)H * W > (1 << 24)) return fail(IDM_ERR_UNSUPPORTED, "lattice too large");
+    return IDM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int idm_abi_version(void) { return IDM_ABI_VERSION; }
+
+const char *idm_last_error(void) { return g_err.c_str(); }
+
+int idm_model_create(idm_model **out, int device, const idm_model_desc *d)
+{
+    if (!out || !d) return fail(IDM_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (d->base_filters != 32) return fail(IDM_ERR_UNSUPPORTED, "base_filters must be 32");
+    if (d->channels != 1 && d->channels != 2) return fail(IDM_ERR_UNSUPPORTED, "channels must be 1 or 2");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(IDM_ERR_INVALID, "no such device");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(IDM_ERR_UNSUPPORTED, std::string("built for gfx950 (MI355X); device is ") + prop.gcnArchName);
+
+    idm_model *m = new idm_model();
+    m->device = device; m->C = d->channels; m->F = d->base_filters; m->bn = d->batchnorm != 0;
+    const int f = m->F, c = m->C;
+    const int cin[IDM_NCONV] = {c, f, f, 2 * f, 2 * f, 4 * f, 6 * f, 2 * f, 3 * f, f, f};
+    const int cout[IDM_NCONV] = {f, f, 2 * f, 2 * f, 4 * f, 4 * f, 2 * f, 2 * f, f, f, c};
+    int rc = IDM_OK;
+    for (int i = 0; i < IDM_NCONV && rc == IDM_OK; ++i) {
+        m->cin[i] = cin[i]; m->cout[i] = cout[i];
+        if (!d->conv_w[i] || !d->conv_b[i]) { rc = fail(IDM_ERR_INVALID, "missing conv weights"); break; }
+        rc = upload(m, d->conv_b[i], (size_t)cout[i], &m->bias[i]);
+        if (rc == IDM_OK && m->bn && i < 10) {
+            if (!d->bn_scale[i] || !d->bn_shift[i]) { rc = fail(IDM_ERR_INVALID, "missing BatchNorm tensors"); break; }
+            rc = upload(m, d->bn_scale[i], (size_t)cout[i], &m->scale[i]);
+            if (rc == IDM_OK) rc = upload(m, d->bn_shift[i], (size_t)cout[i], &m->shift[i]);
+        }
+        if (rc != IDM_OK) break;
+        if (i == 0) rc = upload(m, d->conv_w[0], (size_t)9 * c * f, &m->w_first);
+        else if (i == 10) rc = upload(m, d->conv_w[10], (size_t)f * c, &m->w_head);
+        else {
+            std::vector<uint16_t> pb = pack_weights_bf16(d->conv_w[i], cin[i], cout[i]);
+            std::vector<float> pf = pack_weights_f32(d->conv_w[i], cin[i], cout[i]);
+            rc = upload(m, pb.data(), pb.size(), (uint16_t **)&m->wpack_bf16[i]);
+            if (rc == IDM_OK) rc = upload(m, pf.data(), pf.size(), (float **)&m->wpack_f32[i]);
+        }
+    }
+    const int din[IDM_NDENSE] = {1, 4 * f, 4 * f};
+    for (int i = 0; i < IDM_NDENSE && rc == IDM_OK; ++i) {
+        if (!d->dense_w[i] || !d->dense_b[i]) { rc = fail(IDM_ERR_INVALID, "missing dense weights"); break; }
+        rc = upload(m, d->dense_w[i], (size_t)din[i] * 4 * f, &m->dense_w[i]);
+        if (rc == IDM_OK) rc = upload(m, d->dense_b[i], (size_t)4 * f, &m->dense_b[i]);
+    }
+    if (rc == IDM_OK) {
+        hipError_t e = hipMalloc((void **)&m->trow, (size_t)4 * f * sizeof(float));
+        if (e != hipSuccess) rc = fail(IDM_ERR_NOMEM, "hipMalloc failed");
+        else m->owned.push_back(m->trow);
+    }
+    if (rc != IDM_OK) { std::string keep = g_err; idm_model_destroy(m); g_err = keep; return rc; }
+    *out = m;
+    return IDM_OK;
+}
+
+int idm_model_destroy(idm_model *m)
+{
+    if (!m) return IDM_OK;
+    (void)hipSetDevice(m->device);
+    for (void *p : m->owned) (void)hipFree(p);
+    if (m->ttable) (void)hipFree(m->ttable);
+    if (m->ws) (void)hipFree(m->ws);
+    delete m;
+    return IDM_OK;
+}
+
+int idm_time_table(idm_model *m, int T, float *table_host)
+{
+    if (!m || T <= 0) return fail(IDM_ERR_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(m->device));
+    const int n = 4 * m->F;
+    if (m->ttable_T != T) {
+        if (m->ttable) { HIPCHK(hipFree(m->ttable)); m->ttable = nullptr; m->ttable_T = 0; }
+        HIPCHK(hipMalloc((void **)&m->ttable, (size_t)T * n * sizeof(float)));
+        launch_time_table(T, n, m->dense_w[0], m->dense_b[0], m->dense_w[1], m->dense_b[1], m->dense_w[2],
+                          m->dense_b[2], m->ttable, nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
+        m->ttable_T = T;
+    }
+    if (table_host) HIPCHK(hipMemcpy(table_host, m->ttable, (size_t)T * n * sizeof(float), hipMemcpyDeviceToHost));
+    return IDM_OK;
+}
+
+int idm_forward_taps(idm_model *m, const float *x_dev, float t_norm, float *score_dev, int64_t B, int H, int W,
+                     int precision, float *const *taps_dev, void *stream)
+{
+    int rc = check_shape(m, B, H, W, precision);
+    if (rc != IDM_OK) return rc;
+    if (!x_dev || !score_dev) return fail(IDM_ERR_INVALID, "null tensor");
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const Plan p = make_plan(m, H, W, precision);
+    const int64_t chunk = auto_chunk(p, B);
+    rc = ensure_ws(m, p.per_lattice * (size_t)chunk);
+    if (rc != IDM_OK) return rc;
+    launch_time_row(t_norm, 4 * m->F, m->dense_w[0], m->dense_b[0], m->dense_w[1], m->dense_b[1], m->dense_w[2],
+                    m->dense_b[2], m->trow, s);
+    const size_t elems = (size_t)H * W * m->C;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t bc = std::min(chunk, B - b0);
+        rc = forward_chunk(m, p, x_dev + b0 * elems, m->trow, score_dev + b0 * elems, bc, precision, taps_dev, b0, s);
+        if (rc != IDM_OK) return rc;
+    }
+    return IDM_OK;
+}
+
+int idm_forward(idm_model *m, const float *x_dev, float t_norm, float *score_dev, int64_t B, int H, int W,
+                int precision, void *stream)
+{
+    return idm_forward_taps(m, x_dev, t_norm, score_dev, B, H, W, precision, nullptr, stream);
+}
+
+int idm_sample(idm_model *m, const idm_sample_cfg *cfg, float *x_dev, const float *noise_dev, float *traj_dev,
+               float *scores_dev, int8_t *spins_dev, int64_t B, int H, int W, void *stream)
+{
+    if (!cfg) return fail(IDM_ERR_INVALID, "null cfg");
+    int rc = check_shape(m, B, H, W, cfg->precision);
+    if (rc != IDM_OK) return rc;
+    if (!x_dev) return fail(IDM_ERR_INVALID, "x_dev is null");
+    if (cfg->T <= 0 || !cfg->betas_host) return fail(IDM_ERR_INVALID, "T and betas_host are required");
+    if (cfg->chunk < 0) return fail(IDM_ERR_INVALID, "negative chunk");
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int T = cfg->T;
+    rc = idm_time_table(m, T, nullptr);
+    if (rc != IDM_OK) return rc;
+    const Plan p = make_plan(m, H, W, cfg->precision);
+    int64_t chunk = cfg->chunk > 0 ? std::min<int64_t>(cfg->chunk, B) : auto_chunk(p, B);
+    rc = ensure_ws(m, p.per_lattice * (size_t)chunk);
+    if (rc != IDM_OK) return rc;
+    const size_t elems = (size_t)H * W * m->C;
+    const size_t total = (size_t)B * elems;
+    const int nf = 4 * m->F;
+
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t bc = std::min(chunk, B - b0);
+        float *x = x_dev + b0 * elems;
+        float *score_ws = (float *)(m->ws + p.off_score * (size_t)bc);
+        PhiloxArgs ph;
+        ph.seed = cfg->seed;
+        ph.first_global_index = cfg->first_global_index + b0;
+        if (cfg->init_state) {
+            ph.t = T;
+            launch_philox_normal(x, bc, (int64_t)elems, ph, s);
+        }
+        if (traj_dev)
+            HIPCHK(hipMemcpyAsync(traj_dev + (size_t)T * total + b0 * elems, x, bc * elems * 4, hipMemcpyDeviceToDevice, s));
+        for (int t = T - 1; t >= 0; --t) {
+            float *score = scores_dev ? scores_dev + (size_t)t * total + b0 * elems : score_ws;
+            rc = forward_chunk(m, p, x, m->ttable + (size_t)t * nf, score, bc, cfg->precision, nullptr, 0, s);
+            if (rc != IDM_OK) return rc;
+            ph.t = t;
+            const float *z = noise_dev ? noise_dev + (size_t)t * total + b0 * elems : nullptr;
+            launch_update(x, score, z, cfg->betas_host[t], bc, (int64_t)elems, cfg->add_noise != 0, ph, s);
+            if (traj_dev)
+                HIPCHK(hipMemcpyAsync(traj_dev + (size_t)t * total + b0 * elems, x, bc * elems * 4, hipMemcpyDeviceToDevice, s));
+        }
+        if (spins_dev) launch_sign_project(x, spins_dev + b0 * elems, (int64_t)(bc * elems), s);
+        HIPCHK(hipGetLastError());
+    }
+    return IDM_OK;
+}
+
+int idm_update(int device, float *x_dev, const float *score_dev, const float *z_dev, float beta, int64_t n, void *stream)
+{
+    if (!x_dev || !score_dev || n <= 0) return fail(IDM_ERR_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(device));
+    PhiloxArgs ph = {0, 0, 0};
+    launch_update(x_dev, score_dev, z_dev, beta, 1, n, z_dev != nullptr, ph, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return IDM_OK;
+}
+
+int idm_philox_normal(int device, float *out_dev, int64_t n_lattices, int64_t elems_per_lattice, uint64_t seed,
+                      int64_t first_global_index, int32_t t, void *stream)
+{
+    if (!out_dev || n_lattices <= 0 || elems_per_lattice <= 0) return fail(IDM_ERR_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(device));
+    PhiloxArgs ph = {seed, first_global_index, t};
+    launch_philox_normal(out_dev, n_lattices, elems_per_lattice, ph, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return IDM_OK;
+}
+
+int idm_sign_project(int device, const float *x_dev, int8_t *spins_dev, int64_t n, void *stream)
+{
+    if (!x_dev || !spins_dev || n <= 0) return fail(IDM_ERR_INVALID, "bad argument");
+    HIPCHK(hipSetDevice(device));
+    launch_sign_project(x_dev, spins_dev, n, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return IDM_OK;
+}
+
+int idm_observe(int device, const int8_t *spins_dev, int64_t B, int L, int32_t *M_dev, int32_t *S_dev,
+                unsigned long long *hist_M_dev, unsigned long long *hist_S_dev, long long *moments_dev, void *stream)
+{
+    if (!spins_dev || B <= 0 || L <= 0) return fail(IDM_ERR_INVALID, "bad argument");
+    if (L > 4096) return fail(IDM_ERR_UNSUPPORTED, "L too large");
+    HIPCHK(hipSetDevice(device));
+    launch_observe(spins_dev, B, L, M_dev, S_dev, hist_M_dev, hist_S_dev, moments_dev, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return IDM_OK;
+}
+
+}  // extern "C"

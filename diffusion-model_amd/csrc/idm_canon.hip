@@ -1,0 +1,443 @@
+// Float32 kernels with a fixed ("canonical") arithmetic order, plus the small elementwise,
+// noise and observable kernels shared by both precisions.
+//
+// Canonical order: every contraction is one float32 fma chain from +0 over ascending
+// k = (ky*3 + kx)*Cin + c, bias added afterwards; swish(y) = y / (1 + cexp(-y)) with the
+// polynomial cexp below; pooling (((a+b)+c)+d)*0.25; sampler update with every operation
+// rounded separately.  v_mfma_f32_32x32x2_f32 computes exactly such a chain (k = 0 then
+// k = 1 per instruction), so the matrix-core path reproduces a scalar fmaf loop bit for bit.
+// This file must be compiled with -ffp-contract=off.
+#include "idm_internal.h"
+
+#include <math.h>
+
+#define DEVI __device__ __forceinline__
+
+DEVI float cexp(float x)
+{
+    x = fminf(fmaxf(x, -87.0f), 87.0f);
+    const float n = rintf(__fmul_rn(x, 1.44269504088896341f));
+    float r = __fmaf_rn(n, -0.693359375f, x);
+    r = __fmaf_rn(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __fmaf_rn(p, r, 1.3981999507e-3f);
+    p = __fmaf_rn(p, r, 8.3334519073e-3f);
+    p = __fmaf_rn(p, r, 4.1665795894e-2f);
+    p = __fmaf_rn(p, r, 1.6666665459e-1f);
+    p = __fmaf_rn(p, r, 5.0000001201e-1f);
+    const float r2 = __fmul_rn(r, r);
+    p = __fmaf_rn(p, r2, r);
+    p = __fadd_rn(p, 1.0f);
+    return ldexpf(p, (int)n);
+}
+
+DEVI float csilu(float y) { return __fdiv_rn(y, __fadd_rn(1.0f, cexp(-y))); }
+
+DEVI float epilogue(float acc, int co, const float *bias, const float *scale, const float *shift, int silu,
+                    const float *tadd)
+{
+    float z = __fadd_rn(acc, bias[co]);
+    if (scale) { z = __fmul_rn(z, scale[co]); z = __fadd_rn(z, shift[co]); }
+    if (silu) z = csilu(z);
+    if (tadd) z = __fadd_rn(z, tadd[co]);
+    return z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 conv, float32, v_mfma_f32_32x32x2_f32.  One wave = 32 pixels x all Cout (MT tiles of 32).
+// Operand fetch straight from global memory (this is the parity path, not the fast one).
+// Weights are packed [tap][c/8][mt][lane][4]: element s of lane l is W[tap][8*(c/8)+2s+(l>>5)][32mt+(l&31)].
+// ---------------------------------------------------------------------------------------------
+template <int MT, int MODE>
+__global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t npix = a.B * a.H * a.W;
+    if (tile * 32 >= npix) return;
+    const int64_t p = tile * 32 + (lane & 31);
+    const bool pv = p < npix;
+    const int64_t pc = pv ? p : 0;
+    const int x = (int)(pc % a.W);
+    const int y = (int)((pc / a.W) % a.H);
+    const int64_t b = pc / ((int64_t)a.W * a.H);
+    const int h = lane >> 5;
+    const int Cin = a.C0 + a.C1;
+    const int ncg = Cin >> 3;
+    const float *in0 = (const float *)a.in0;
+    const float *in1 = (const float *)a.in1;
+    const f32x4 *wp = (const f32x4 *)a.wpack + lane;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        const bool inb = pv && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+        for (int cg = 0; cg < ncg; ++cg) {
+            const int c = cg * 8;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+            if (inb) {
+                if (MODE == CONV_PLAIN) {
+                    const f32x4 *q = (const f32x4 *)(in0 + ((b * a.H + yy) * a.W + xx) * a.C0 + c);
+                    const f32x4 q0 = q[0], q1 = q[1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = q0[j]; v[4 + j] = q1[j]; }
+                } else if (MODE == CONV_POOL) {
+                    const int H2 = 2 * a.H, W2 = 2 * a.W;
+                    const float *q = in0 + ((b * H2 + 2 * yy) * W2 + 2 * xx) * a.C0 + c;
+                    const f32x4 *q00 = (const f32x4 *)q, *q01 = (const f32x4 *)(q + a.C0);
+                    const f32x4 *q10 = (const f32x4 *)(q + (int64_t)W2 * a.C0), *q11 = (const f32x4 *)(q + (int64_t)W2 * a.C0 + a.C0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const f32x4 t0 = q00[u], t1 = q01[u], t2 = q10[u], t3 = q11[u];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            v[4 * u + j] = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(t0[j], t1[j]), t2[j]), t3[j]), 0.25f);
+                    }
+                } else {
+                    const f32x4 *q;
+                    if (c < a.C0) {
+                        const int Hh = a.H >> 1, Wh = a.W >> 1;
+                        q = (const f32x4 *)(in0 + ((b * Hh + (yy >> 1)) * Wh + (xx >> 1)) * a.C0 + c);
+                    } else {
+                        q = (const f32x4 *)(in1 + ((b * a.H + yy) * a.W + xx) * a.C1 + (c - a.C0));
+                    }
+                    const f32x4 q0 = q[0], q1 = q[1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = q0[j]; v[4 + j] = q1[j]; }
+                }
+            }
+            const f32x4 *w = wp + (int64_t)(tap * ncg + cg) * MT * 64;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const f32x4 wv = w[m * 64];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float bv = h ? v[2 * s + 1] : v[2 * s];
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[s], bv, acc[m], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!pv) return;
+    float *out = (float *)a.out + p * a.Cout;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            out[co] = epilogue(acc[m][r], co, a.bias, a.scale, a.shift, a.silu, a.tadd);
+        }
+}
+
+template <int MT>
+static void launch_conv_f32_mt(const ConvArgs &a, hipStream_t s)
+{
+    const int64_t npix = a.B * a.H * a.W;
+    const unsigned grid = (unsigned)((npix + 127) / 128);
+    switch (a.mode) {
+    case CONV_PLAIN: hipLaunchKernelGGL((conv3x3_f32_kernel<MT, CONV_PLAIN>), dim3(grid), dim3(256), 0, s, a); break;
+    case CONV_POOL: hipLaunchKernelGGL((conv3x3_f32_kernel<MT, CONV_POOL>), dim3(grid), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((conv3x3_f32_kernel<MT, CONV_UPCAT>), dim3(grid), dim3(256), 0, s, a); break;
+    }
+}
+
+void launch_conv_f32(const ConvArgs &a, hipStream_t s)
+{
+    switch (a.Cout / 32) {
+    case 1: launch_conv_f32_mt<1>(a, s); break;
+    case 2: launch_conv_f32_mt<2>(a, s); break;
+    default: launch_conv_f32_mt<4>(a, s); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// First layer: Cin = C in {1,2}, K = 9C is too thin for matrix cores.  One thread per pixel,
+// canonical chain, reads the unpadded state (B,H,W,C) and writes the padded map (B,Hp,Wp,32).
+// ---------------------------------------------------------------------------------------------
+template <typename OutT>
+__global__ __launch_bounds__(256) void conv_first_kernel(const float *__restrict__ x, int64_t B, int H, int W, int Hp,
+                                                         int Wp, int C, const float *__restrict__ w,
+                                                         const float *__restrict__ bias, const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, OutT *__restrict__ out)
+{
+    __shared__ float ws[9 * 2 * 32];
+    __shared__ float bs[3 * 32];
+    for (int i = threadIdx.x; i < 9 * C * 32; i += 256) ws[i] = w[i];
+    if (threadIdx.x < 32) {
+        bs[threadIdx.x] = bias[threadIdx.x];
+        bs[32 + threadIdx.x] = scale ? scale[threadIdx.x] : 1.0f;
+        bs[64 + threadIdx.x] = shift ? shift[threadIdx.x] : 0.0f;
+    }
+    __syncthreads();
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= B * Hp * Wp) return;
+    const int xo = (int)(p % Wp), yo = (int)((p / Wp) % Hp);
+    const int64_t b = p / ((int64_t)Wp * Hp);
+    float acc[32];
+#pragma unroll
+    for (int f = 0; f < 32; ++f) acc[f] = 0.0f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = yo + tap / 3 - 1, xx = xo + tap % 3 - 1;
+        // taps outside the padded map contribute nothing; taps in the zero padding contribute 0*w
+        if (yy < 0 || yy >= Hp || xx < 0 || xx >= Wp) continue;
+        for (int c = 0; c < C; ++c) {
+            const float v = (yy < H && xx < W) ? x[((b * H + yy) * W + xx) * C + c] : 0.0f;
+            const float *wr = ws + (tap * C + c) * 32;
+#pragma unroll
+            for (int f = 0; f < 32; ++f) acc[f] = __fmaf_rn(v, wr[f], acc[f]);
+        }
+    }
+    OutT *o = out + p * 32;
+#pragma unroll
+    for (int f = 0; f < 32; ++f) {
+        float z = __fadd_rn(acc[f], bs[f]);
+        if (scale) { z = __fmul_rn(z, bs[32 + f]); z = __fadd_rn(z, bs[64 + f]); }
+        o[f] = (OutT)csilu(z);
+    }
+}
+
+void launch_conv_first(const float *x, int64_t B, int H, int W, int Hp, int Wp, int C, const float *w,
+                       const float *bias, const float *scale, const float *shift, void *out, int F, bool out_bf16,
+                       hipStream_t s)
+{
+    (void)F;
+    const unsigned grid = (unsigned)((B * Hp * Wp + 255) / 256);
+    if (out_bf16)
+        hipLaunchKernelGGL(conv_first_kernel<__bf16>, dim3(grid), dim3(256), 0, s, x, B, H, W, Hp, Wp, C, w, bias, scale,
+                           shift, (__bf16 *)out);
+    else
+        hipLaunchKernelGGL(conv_first_kernel<float>, dim3(grid), dim3(256), 0, s, x, B, H, W, Hp, Wp, C, w, bias, scale,
+                           shift, (float *)out);
+}
+
+// Head: 1x1 conv F -> C (linear) on the float32 output of the last 3x3 layer, cropped to (H,W).
+__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ a9, int64_t B, int H, int W, int Hp, int Wp,
+                                                   int F, int C, const float *__restrict__ w,
+                                                   const float *__restrict__ bias, float *__restrict__ score)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= B * H * W) return;
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    const int64_t b = p / ((int64_t)W * H);
+    const float *ip = a9 + ((b * Hp + y) * Wp + x) * F;
+    for (int ch = 0; ch < C; ++ch) {
+        float acc = 0.0f;
+        for (int f = 0; f < F; ++f) acc = __fmaf_rn(ip[f], w[f * C + ch], acc);
+        score[p * C + ch] = __fadd_rn(acc, bias[ch]);
+    }
+}
+
+void launch_head(const float *a9, int64_t B, int H, int W, int Hp, int Wp, int F, int C, const float *w,
+                 const float *bias, float *score, hipStream_t s)
+{
+    const unsigned grid = (unsigned)((B * H * W + 255) / 256);
+    hipLaunchKernelGGL(head_kernel, dim3(grid), dim3(256), 0, s, a9, B, H, W, Hp, Wp, F, C, w, bias, score);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11) keyed by the seed; counter = (quad index within the
+// lattice, global lattice index low, global lattice index high, step t).  Four outputs give four
+// standard normals (two Box-Muller pairs) for four consecutive elements of one lattice, so a
+// draw depends only on (seed, global lattice, element, t) and never on batch size or sharding.
+// ---------------------------------------------------------------------------------------------
+DEVI void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+DEVI float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * 5.9604644775390625e-08f; }  // (0,1), exact
+
+DEVI void normal4(uint64_t seed, int64_t lattice, uint32_t quad, int32_t t, float z[4])
+{
+    uint32_t r[4];
+    philox4x32_10(quad, (uint32_t)lattice, (uint32_t)((uint64_t)lattice >> 32), (uint32_t)t, (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    const float m0 = sqrtf(-2.0f * logf(u01(r[0]))), m1 = sqrtf(-2.0f * logf(u01(r[2])));
+    float s0, c0, s1, c1;
+    sincospif(2.0f * u01(r[1]), &s0, &c0);
+    sincospif(2.0f * u01(r[3]), &s1, &c1);
+    z[0] = m0 * c0; z[1] = m0 * s0; z[2] = m1 * c1; z[3] = m1 * s1;
+}
+
+// x <- ((c1*x) + (beta*score)) + z*sqrt(beta).  One thread per quad of four consecutive elements.
+__global__ __launch_bounds__(256) void update_kernel(float *__restrict__ x, const float *__restrict__ score,
+                                                     const float *__restrict__ zin, float c1, float beta, float sd,
+                                                     int64_t n_lattices, int64_t elems, int add_noise, PhiloxArgs ph)
+{
+    const int64_t nq = (elems + 3) >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_lattices * nq) return;
+    const int64_t b = i / nq;
+    const uint32_t q = (uint32_t)(i % nq);
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (add_noise && !zin) normal4(ph.seed, ph.first_global_index + b, q, ph.t, z);
+    const int64_t base = b * elems + (int64_t)q * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if ((int64_t)q * 4 + j >= elems) break;
+        const int64_t e = base + j;
+        float v = __fadd_rn(__fmul_rn(c1, x[e]), __fmul_rn(beta, score[e]));
+        if (add_noise) v = __fadd_rn(v, __fmul_rn(zin ? zin[e] : z[j], sd));
+        x[e] = v;
+    }
+}
+
+void launch_update(float *x, const float *score, const float *z, float beta, int64_t n_lattices, int64_t elems,
+                   bool add_noise, const PhiloxArgs &ph, hipStream_t s)
+{
+    const int64_t nq = (elems + 3) >> 2;
+    const unsigned grid = (unsigned)((n_lattices * nq + 255) / 256);
+    // The three step constants are rounded on the host (IEEE single, one operation each) so that
+    // they do not depend on the device's square-root implementation.
+    volatile float half_beta = 0.5f * beta;
+    volatile float c1 = 1.0f + half_beta;
+    volatile float sd = sqrtf(beta);
+    hipLaunchKernelGGL(update_kernel, dim3(grid), dim3(256), 0, s, x, score, z, (float)c1, beta, (float)sd, n_lattices,
+                       elems, add_noise ? 1 : 0, ph);
+}
+
+__global__ __launch_bounds__(256) void philox_normal_kernel(float *__restrict__ out, int64_t n_lattices, int64_t elems,
+                                                            PhiloxArgs ph)
+{
+    const int64_t nq = (elems + 3) >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_lattices * nq) return;
+    const int64_t b = i / nq;
+    const uint32_t q = (uint32_t)(i % nq);
+    float z[4];
+    normal4(ph.seed, ph.first_global_index + b, q, ph.t, z);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if ((int64_t)q * 4 + j < elems) out[b * elems + (int64_t)q * 4 + j] = z[j];
+}
+
+void launch_philox_normal(float *out, int64_t n_lattices, int64_t elems, const PhiloxArgs &ph, hipStream_t s)
+{
+    const int64_t nq = (elems + 3) >> 2;
+    const unsigned grid = (unsigned)((n_lattices * nq + 255) / 256);
+    hipLaunchKernelGGL(philox_normal_kernel, dim3(grid), dim3(256), 0, s, out, n_lattices, elems, ph);
+}
+
+// Time-embedding table: row t = Dense2(Dense1(swish(Dense0(t/T)))) — one block per t, canonical chains.
+__global__ __launch_bounds__(128) void time_table_kernel(int T, int n, int single, float tn_single,
+                                                         const float *__restrict__ w0,
+                                                         const float *__restrict__ b0, const float *__restrict__ w1,
+                                                         const float *__restrict__ b1, const float *__restrict__ w2,
+                                                         const float *__restrict__ b2, float *__restrict__ table)
+{
+    __shared__ float e0[128], e1[128];
+    const int t = blockIdx.x, j = threadIdx.x;
+    const float tn = single ? tn_single : __fdiv_rn((float)t, (float)T);
+    if (j < n) e0[j] = csilu(__fadd_rn(__fmaf_rn(tn, w0[j], 0.0f), b0[j]));
+    __syncthreads();
+    if (j < n) {
+        float acc = 0.0f;
+        for (int i = 0; i < n; ++i) acc = __fmaf_rn(e0[i], w1[i * n + j], acc);
+        e1[j] = __fadd_rn(acc, b1[j]);
+    }
+    __syncthreads();
+    if (j < n) {
+        float acc = 0.0f;
+        for (int i = 0; i < n; ++i) acc = __fmaf_rn(e1[i], w2[i * n + j], acc);
+        table[(int64_t)t * n + j] = __fadd_rn(acc, b2[j]);
+    }
+}
+
+void launch_time_table(int T, int n, const float *w0, const float *b0, const float *w1, const float *b1,
+                       const float *w2, const float *b2, float *table, hipStream_t s)
+{
+    hipLaunchKernelGGL(time_table_kernel, dim3(T), dim3(128), 0, s, T, n, 0, 0.0f, w0, b0, w1, b1, w2, b2, table);
+}
+
+void launch_time_row(float t_norm, int n, const float *w0, const float *b0, const float *w1, const float *b1,
+                     const float *w2, const float *b2, float *row, hipStream_t s)
+{
+    hipLaunchKernelGGL(time_table_kernel, dim3(1), dim3(128), 0, s, 1, n, 1, t_norm, w0, b0, w1, b1, w2, b2, row);
+}
+
+__global__ __launch_bounds__(256) void sign_project_kernel(const float *__restrict__ x, int8_t *__restrict__ spins, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) spins[i] = x[i] > 0.0f ? 1 : -1;
+}
+
+void launch_sign_project(const float *x, int8_t *spins, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(sign_project_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, spins, n);
+}
+
+// Observables: one 64-lane wavefront per lattice.  Lanes stride over the sites, each adds
+// s, s*s_down and s*s_right (periodic), then a wavefront shuffle reduction; lane 0 writes
+// M, S and bumps the histograms / moments with device-scope integer atomics.
+__global__ __launch_bounds__(256) void observe_kernel(const int8_t *__restrict__ spins, int64_t B, int L,
+                                                      int32_t *__restrict__ M, int32_t *__restrict__ S,
+                                                      unsigned long long *__restrict__ histM,
+                                                      unsigned long long *__restrict__ histS,
+                                                      long long *__restrict__ moments)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int8_t *s = spins + b * L * L;
+    int m = 0, bond = 0;
+    for (int i = lane; i < L * L; i += 64) {
+        const int y = i / L, x = i - y * L;
+        const int v = s[i];
+        const int d = s[(y + 1 == L ? 0 : y + 1) * L + x];
+        const int r = s[y * L + (x + 1 == L ? 0 : x + 1)];
+        m += v;
+        bond += v * d + v * r;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m += __shfl_down(m, off, 64);
+        bond += __shfl_down(bond, off, 64);
+    }
+    if (lane == 0) {
+        if (M) M[b] = m;
+        if (S) S[b] = bond;
+        if (histM) atomicAdd(&histM[(m + L * L) / 2], 1ull);
+        if (histS) atomicAdd(&histS[(bond + 2 * L * L) / 2], 1ull);
+        if (moments) {
+            atomicAdd((unsigned long long *)&moments[0], 1ull);
+            atomicAdd((unsigned long long *)&moments[1], (unsigned long long)(long long)m);
+            atomicAdd((unsigned long long *)&moments[2], (unsigned long long)(long long)(m < 0 ? -m : m));
+            atomicAdd((unsigned long long *)&moments[3], (unsigned long long)((long long)m * m));
+            atomicAdd((unsigned long long *)&moments[4], (unsigned long long)(long long)bond);
+            atomicAdd((unsigned long long *)&moments[5], (unsigned long long)((long long)bond * bond));
+        }
+    }
+}
+
+void launch_observe(const int8_t *spins, int64_t B, int L, int32_t *M, int32_t *S, unsigned long long *histM,
+                    unsigned long long *histS, long long *moments, hipStream_t s)
+{
+    hipLaunchKernelGGL(observe_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, spins, B, L, M, S, histM, histS,
+                       moments);
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const __bf16 *__restrict__ in, float *__restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
+void launch_cast_bf16_to_f32(const void *in, float *out, int64_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const __bf16 *)in, out, n);
+}

@@ -1,0 +1,117 @@
+// bf16 matrix-core kernels: activations and weights bfloat16, accumulation float32.
+#include "idm_internal.h"
+
+#define DEVI __device__ __forceinline__
+
+DEVI float fast_silu(float y) { return y / (1.0f + __expf(-y)); }
+
+// ---------------------------------------------------------------------------------------------
+// Generic per-layer 3x3 conv, v_mfma_f32_32x32x16_bf16, operands fetched straight from global
+// memory.  One wave = 32 pixels x all Cout.  Used for shapes the fused kernels do not cover.
+// Weights packed [tap][c/16][mt][lane][8]: element j of lane l is W[tap][16*(c/16)+8*(l>>5)+j][32mt+(l&31)].
+// ---------------------------------------------------------------------------------------------
+template <int MT, int MODE>
+__global__ __launch_bounds__(256) void conv3x3_bf16_direct_kernel(ConvArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t npix = a.B * a.H * a.W;
+    if (tile * 32 >= npix) return;
+    const int64_t p = tile * 32 + (lane & 31);
+    const bool pv = p < npix;
+    const int64_t pc = pv ? p : 0;
+    const int x = (int)(pc % a.W);
+    const int y = (int)((pc / a.W) % a.H);
+    const int64_t b = pc / ((int64_t)a.W * a.H);
+    const int h = lane >> 5;
+    const int Cin = a.C0 + a.C1;
+    const int ncg = Cin >> 4;
+    const __bf16 *in0 = (const __bf16 *)a.in0;
+    const __bf16 *in1 = (const __bf16 *)a.in1;
+    const bf16x8 *wp = (const bf16x8 *)a.wpack + lane;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        const bool inb = pv && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+        for (int cg = 0; cg < ncg; ++cg) {
+            const int c = cg * 16 + 8 * h;
+            bf16x8 bv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bv[j] = (__bf16)0.0f;
+            if (inb) {
+                if (MODE == CONV_PLAIN) {
+                    bv = *(const bf16x8 *)(in0 + ((b * a.H + yy) * a.W + xx) * a.C0 + c);
+                } else if (MODE == CONV_POOL) {
+                    const int H2 = 2 * a.H, W2 = 2 * a.W;
+                    const __bf16 *q = in0 + ((b * H2 + 2 * yy) * W2 + 2 * xx) * a.C0 + c;
+                    const bf16x8 t0 = *(const bf16x8 *)q, t1 = *(const bf16x8 *)(q + a.C0);
+                    const bf16x8 t2 = *(const bf16x8 *)(q + (int64_t)W2 * a.C0);
+                    const bf16x8 t3 = *(const bf16x8 *)(q + (int64_t)W2 * a.C0 + a.C0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        bv[j] = (__bf16)((((float)t0[j] + (float)t1[j]) + (float)t2[j] + (float)t3[j]) * 0.25f);
+                } else {
+                    if (c < a.C0) {
+                        const int Hh = a.H >> 1, Wh = a.W >> 1;
+                        bv = *(const bf16x8 *)(in0 + ((b * Hh + (yy >> 1)) * Wh + (xx >> 1)) * a.C0 + c);
+                    } else {
+                        bv = *(const bf16x8 *)(in1 + ((b * a.H + yy) * a.W + xx) * a.C1 + (c - a.C0));
+                    }
+                }
+            }
+            const bf16x8 *w = wp + (int64_t)(tap * ncg + cg) * MT * 64;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[m * 64], bv, acc[m], 0, 0, 0);
+        }
+    }
+    if (!pv) return;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = m * 32 + 8 * g + 4 * h;
+            float z[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = acc[m][4 * g + j] + a.bias[co + j];
+                if (a.scale) v = v * a.scale[co + j] + a.shift[co + j];
+                if (a.silu) v = fast_silu(v);
+                if (a.tadd) v += a.tadd[co + j];
+                z[j] = v;
+            }
+            if (a.out_f32) {
+                f32x4 o = {z[0], z[1], z[2], z[3]};
+                *(f32x4 *)((float *)a.out + p * a.Cout + co) = o;
+            } else {
+                bf16x4 o = {(__bf16)z[0], (__bf16)z[1], (__bf16)z[2], (__bf16)z[3]};
+                *(bf16x4 *)((__bf16 *)a.out + p * a.Cout + co) = o;
+            }
+        }
+}
+
+template <int MT>
+static void launch_conv_bf16_mt(const ConvArgs &a, hipStream_t s)
+{
+    const int64_t npix = a.B * a.H * a.W;
+    const unsigned grid = (unsigned)((npix + 127) / 128);
+    switch (a.mode) {
+    case CONV_PLAIN: hipLaunchKernelGGL((conv3x3_bf16_direct_kernel<MT, CONV_PLAIN>), dim3(grid), dim3(256), 0, s, a); break;
+    case CONV_POOL: hipLaunchKernelGGL((conv3x3_bf16_direct_kernel<MT, CONV_POOL>), dim3(grid), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((conv3x3_bf16_direct_kernel<MT, CONV_UPCAT>), dim3(grid), dim3(256), 0, s, a); break;
+    }
+}
+
+void launch_conv_bf16(const ConvArgs &a, hipStream_t s)
+{
+    switch (a.Cout / 32) {
+    case 1: launch_conv_bf16_mt<1>(a, s); break;
+    case 2: launch_conv_bf16_mt<2>(a, s); break;
+    default: launch_conv_bf16_mt<4>(a, s); break;
+    }
+}

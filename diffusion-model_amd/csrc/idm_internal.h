@@ -1,0 +1,65 @@
+// Internal interface between the C-ABI translation unit and the kernel translation units.
+// Nothing here is exported from libisingdiff.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+enum ConvMode { CONV_PLAIN = 0, CONV_POOL = 1, CONV_UPCAT = 2 };
+
+// One 3x3 "same" convolution layer as an implicit GEMM  D[cout][pixel] = sum_k W[cout][k] X[k][pixel],
+// k = (ky*3 + kx)*Cin + c.  NHWC tensors.  The loader modes fold the UNet's data movement into
+// the operand fetch:
+//   CONV_PLAIN  in0 is (B,H,W,C0)
+//   CONV_POOL   in0 is (B,2H,2W,C0); the operand is its 2x2 average
+//   CONV_UPCAT  in0 is (B,H/2,W/2,C0) read with nearest upsampling, channels [C0, C0+C1) come
+//               from in1 (B,H,W,C1): Concatenate([UpSampling2D(x), skip])
+struct ConvArgs {
+    const void *in0;
+    const void *in1;
+    int C0, C1;
+    int H, W;            // output (= conv input) spatial size
+    int64_t B;
+    const void *wpack;   // fragment-ordered weights (see pack_weights_* in idm_api.cpp)
+    const float *bias;
+    const float *scale;  // folded BatchNorm or nullptr
+    const float *shift;
+    const float *tadd;   // per-channel add applied after the activation, or nullptr
+    void *out;           // (B,H,W,Cout)
+    int Cout;
+    int mode;
+    int silu;
+    int out_f32;         // bf16 pipeline only: store float32 instead of bf16
+};
+
+struct PhiloxArgs {
+    uint64_t seed;
+    int64_t first_global_index;
+    int32_t t;
+};
+
+// ---- float32 canonical-order kernels (idm_canon.hip) ----
+void launch_conv_f32(const ConvArgs &a, hipStream_t s);
+void launch_conv_first(const float *x, int64_t B, int H, int W, int Hp, int Wp, int C, const float *w,
+                       const float *bias, const float *scale, const float *shift, void *out, int F,
+                       bool out_bf16, hipStream_t s);
+void launch_head(const float *a9, int64_t B, int H, int W, int Hp, int Wp, int F, int C, const float *w,
+                 const float *bias, float *score, hipStream_t s);
+void launch_update(float *x, const float *score, const float *z, float beta, int64_t n_lattices,
+                   int64_t elems, bool add_noise, const PhiloxArgs &ph, hipStream_t s);
+void launch_philox_normal(float *out, int64_t n_lattices, int64_t elems, const PhiloxArgs &ph, hipStream_t s);
+void launch_time_table(int T, int n, const float *w0, const float *b0, const float *w1, const float *b1,
+                       const float *w2, const float *b2, float *table, hipStream_t s);
+void launch_time_row(float t_norm, int n, const float *w0, const float *b0, const float *w1, const float *b1,
+                     const float *w2, const float *b2, float *row, hipStream_t s);
+void launch_sign_project(const float *x, int8_t *spins, int64_t n, hipStream_t s);
+void launch_observe(const int8_t *spins, int64_t B, int L, int32_t *M, int32_t *S, unsigned long long *histM,
+                    unsigned long long *histS, long long *moments, hipStream_t s);
+void launch_cast_bf16_to_f32(const void *in, float *out, int64_t n, hipStream_t s);
+
+// ---- bf16 kernels (idm_fast.hip) ----
+void launch_conv_bf16(const ConvArgs &a, hipStream_t s);

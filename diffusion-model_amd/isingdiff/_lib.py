@@ -1,0 +1,85 @@
+"""ctypes binding of ``libisingdiff.so`` (declared in ``include/isingdiff.h``).
+
+The library is built in-tree by ``csrc/Makefile`` (``__graft_entry__.build()``).  There is
+no CPU fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libisingdiff.so")
+
+IDM_FP32 = 0
+IDM_BF16 = 1
+NCONV = 11
+NDENSE = 3
+ABI_VERSION = 1
+
+
+class IdmError(RuntimeError):
+    pass
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("channels", C.c_int32), ("base_filters", C.c_int32), ("batchnorm", C.c_int32), ("reserved", C.c_int32),
+        ("conv_w", C.c_void_p * NCONV), ("conv_b", C.c_void_p * NCONV),
+        ("bn_scale", C.c_void_p * NCONV), ("bn_shift", C.c_void_p * NCONV),
+        ("dense_w", C.c_void_p * NDENSE), ("dense_b", C.c_void_p * NDENSE),
+    ]
+
+
+class SampleCfg(C.Structure):
+    _fields_ = [
+        ("T", C.c_int32), ("precision", C.c_int32), ("betas_host", C.c_void_p), ("seed", C.c_uint64),
+        ("first_global_index", C.c_int64), ("init_state", C.c_int32), ("add_noise", C.c_int32),
+        ("chunk", C.c_int64),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/isingdiff.h declares
+SIGNATURES = {
+    "idm_abi_version": (C.c_int, []),
+    "idm_last_error": (C.c_char_p, []),
+    "idm_model_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(ModelDesc)]),
+    "idm_model_destroy": (C.c_int, [C.c_void_p]),
+    "idm_time_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "idm_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "idm_forward_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                   C.POINTER(C.c_void_p), C.c_void_p]),
+    "idm_sample": (C.c_int, [C.c_void_p, C.POINTER(SampleCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "idm_update": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
+    "idm_philox_normal": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_int32, C.c_void_p]),
+    "idm_sign_project": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "idm_observe": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and bind every exported symbol."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IdmError(f"{LIB_PATH} not found: build it with `make -C diffusion-model_amd/csrc` "
+                           "(there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.idm_abi_version() != ABI_VERSION:
+            raise IdmError("libisingdiff.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().idm_last_error()
+        raise IdmError(f"libisingdiff error {rc}: {msg.decode() if msg else '?'}")

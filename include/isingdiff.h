@@ -1,0 +1,143 @@
+/*
+ * isingdiff.h — C ABI of libisingdiff.so: reverse-diffusion sampling of 2-D Ising lattices with
+ * the reference's UNet score model on AMD MI355X (gfx950).
+ *
+ * The reference (Mizuki-OHASHI/diffusion-model) has no FFI of its own; the seam this library
+ * sits behind is two Python callables in b_diffusion_model_unet_2d_ising.py:
+ *     score_model([x, t_norm])                               (:88, built by create_unet_model :22-78)
+ *     diffusion_backward(x_asym, beta_lst, score_model, T)   (:81-98)
+ * plus the post-processing that follows them (:209-213 and b_pure_metoropolis_2d_ising.py:42-60).
+ * Each entry point below names the reference lines it replaces.
+ *
+ * Conventions
+ *   - Every function returns IDM_OK (0) or a negative idm_status; idm_last_error() then holds a
+ *     message (thread-local, valid until the next call on that thread).  No C++ types or
+ *     exceptions cross this boundary.
+ *   - Pointers named *_dev are device pointers valid on the model's GPU; pointers named *_host
+ *     are ordinary host memory.  The caller owns every buffer it passes.
+ *   - Tensors are dense, NHWC, little-endian: state and score are float32 (B,H,W,C).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls enqueue work
+ *     on that stream and return without synchronising unless stated otherwise.
+ *   - A model handle is bound to one device and is not thread-safe; distinct handles are.
+ */
+#ifndef ISINGDIFF_H
+#define ISINGDIFF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IDM_ABI_VERSION 1
+
+typedef enum {
+    IDM_OK = 0,
+    IDM_ERR_INVALID = -1,   /* bad argument (null pointer, unsupported shape, …) */
+    IDM_ERR_HIP = -2,       /* a HIP runtime call failed */
+    IDM_ERR_NOMEM = -3,     /* device or host allocation failed */
+    IDM_ERR_UNSUPPORTED = -4
+} idm_status;
+
+typedef enum {
+    IDM_FP32 = 0,  /* float32 activations, float32 MFMA; canonical summation order (deterministic parity mode) */
+    IDM_BF16 = 1   /* bfloat16 activations and weights on bf16 MFMA, float32 accumulate / state */
+} idm_precision;
+
+#define IDM_NCONV 11
+#define IDM_NDENSE 3
+
+/* Weights of the UNet of create_unet_model (b_diffusion_model_unet_2d_ising.py:22-78; BatchNorm
+ * variant b_diffusion_model_fft_unet_2d_ising.py:25-92), as host float32 arrays in Keras order:
+ * conv kernels (kh,kw,Cin,Cout), dense kernels (in,out).  bn_scale/bn_shift are the folded
+ * inference BatchNorm (scale = gamma/sqrt(var+eps), shift = beta - mean*scale) or all NULL. */
+typedef struct {
+    int32_t channels;       /* C of the state tensor: 1 (real space) or 2 (Re,Im) */
+    int32_t base_filters;   /* 32 in the saved models */
+    int32_t batchnorm;      /* 0 / 1 */
+    int32_t reserved;
+    const float *conv_w[IDM_NCONV];
+    const float *conv_b[IDM_NCONV];
+    const float *bn_scale[IDM_NCONV];
+    const float *bn_shift[IDM_NCONV];
+    const float *dense_w[IDM_NDENSE];
+    const float *dense_b[IDM_NDENSE];
+} idm_model_desc;
+
+typedef struct idm_model idm_model;
+
+/* Reverse-schedule configuration (b_diffusion_model_unet_2d_ising.py:168-172 for betas). */
+typedef struct {
+    int32_t T;                    /* number of steps; t runs T-1 .. 0 */
+    int32_t precision;            /* idm_precision */
+    const float *betas_host;      /* T float32 values */
+    uint64_t seed;                /* Philox key (used when noise_dev == NULL and/or x_dev is initialised here) */
+    int64_t first_global_index;   /* global index of lattice 0 of this call: RNG counters use
+                                     first_global_index + b, so results do not depend on sharding */
+    int32_t init_state;           /* 1: draw x_T ~ N(0,1) from Philox into x_dev first; 0: x_dev holds x_T */
+    int32_t add_noise;            /* 1: add noise every step (reference behaviour); 0: deterministic drift only */
+    int64_t chunk;                /* lattices processed together (bounds the workspace); 0 = automatic */
+} idm_sample_cfg;
+
+int idm_abi_version(void);
+const char *idm_last_error(void);
+
+/* keras.models.load_model(...) (:199-201): copies and repacks the weights onto `device`. */
+int idm_model_create(idm_model **out, int device, const idm_model_desc *desc);
+int idm_model_destroy(idm_model *m);
+
+/* The time-embedding sub-graph (:36-38, :56) evaluated for t_norm = float32(t)/float32(T),
+ * t = 0..T-1: a (T, 4*base_filters) float32 table.  Cached in the handle; copied to
+ * table_host when it is not NULL (synchronises). */
+int idm_time_table(idm_model *m, int T, float *table_host);
+
+/* score = score_model([x, t_norm]) (:88).  x_dev, score_dev: (B,H,W,C) float32; every lattice
+ * shares t_norm.  H and W are arbitrary (zero-padded to a multiple of 4 and cropped, :29-34,:76). */
+int idm_forward(idm_model *m, const float *x_dev, float t_norm, float *score_dev,
+                int64_t B, int H, int W, int precision, void *stream);
+
+/* Optional taps for tests: like idm_forward, and copies layer i's activation (padded size,
+ * float32, (B,h_i,w_i,c_i)) to taps_dev[i] for every non-NULL entry, i = 0..10. */
+int idm_forward_taps(idm_model *m, const float *x_dev, float t_norm, float *score_dev,
+                     int64_t B, int H, int W, int precision, float *const *taps_dev, void *stream);
+
+/* diffusion_backward (:81-98) followed by the sign projection (:209-213).
+ *   x_dev       (B,H,W,C) float32: x_T on entry (or filled here when cfg->init_state), final state on return
+ *   noise_dev   NULL, or (T, B,H,W,C) float32 standard normals indexed by t (deterministic mode:
+ *               the step adds noise_dev[t] * sqrt(beta_t)); NULL draws them in-kernel from Philox
+ *   traj_dev    NULL, or (T+1, B,H,W,C): traj[T] = x_T, traj[t] = state after step t (reference return layout)
+ *   scores_dev  NULL, or (T, B,H,W,C): the score used at step t
+ *   spins_dev   NULL, or (B,H,W,C) int8: x > 0 ? +1 : -1 of the final state */
+int idm_sample(idm_model *m, const idm_sample_cfg *cfg, float *x_dev, const float *noise_dev,
+               float *traj_dev, float *scores_dev, int8_t *spins_dev,
+               int64_t B, int H, int W, void *stream);
+
+/* One reverse step on caller-held tensors: x <- ((1 + 0.5*beta)*x + beta*score) + z*sqrt(beta) (:96);
+ * z_dev may be NULL (no noise).  n = element count. */
+int idm_update(int device, float *x_dev, const float *score_dev, const float *z_dev, float beta,
+               int64_t n, void *stream);
+
+/* Fills out_dev (n_lattices, elems_per_lattice) with the standard normals the sampler draws at
+ * step t for lattices first_global_index .. +n_lattices (t = T gives the x_T draw). */
+int idm_philox_normal(int device, float *out_dev, int64_t n_lattices, int64_t elems_per_lattice,
+                      uint64_t seed, int64_t first_global_index, int32_t t, void *stream);
+
+/* np.where(x > 0, 1, -1) (:211).  n = element count. */
+int idm_sign_project(int device, const float *x_dev, int8_t *spins_dev, int64_t n, void *stream);
+
+/* ising_energy / ising_magnetization (b_pure_metoropolis_2d_ising.py:42-60) for ±1 spins
+ * (B,L,L) int8, periodic boundaries, each bond once:
+ *   M_dev[b] = sum s,  S_dev[b] = sum s*s_down + s*s_right   (energy = -J*S - h*M, magnetisation = M/L^2)
+ *   hist_M_dev[(M + L*L)/2]   += 1   (L*L + 1 bins, uint64)
+ *   hist_S_dev[(S + 2*L*L)/2] += 1   (2*L*L + 1 bins, uint64)
+ *   moments_dev[0..5] += {count, sum M, sum |M|, sum M^2, sum S, sum S^2}   (int64)
+ * Histogram and moment buffers accumulate (zero them first); any output pointer may be NULL. */
+int idm_observe(int device, const int8_t *spins_dev, int64_t B, int L, int32_t *M_dev, int32_t *S_dev,
+                unsigned long long *hist_M_dev, unsigned long long *hist_S_dev, long long *moments_dev,
+                void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISINGDIFF_H */

@@ -1,0 +1,174 @@
+"""TEST INFRASTRUCTURE — ctypes binding of ``oracle/ref_cpu.c`` (the C restatement).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this.  See ``ref_cpu.c`` for what it follows in the reference and for the parity status
+("parity unpinned": the reference holds no golden vectors for this path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libref_cpu.so")
+    src = os.path.join(_HERE, "ref_cpu.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libref_cpu.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        pp = C.POINTER(C.c_void_p)
+        L.ref_model_create.restype = C.c_void_p
+        L.ref_model_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, pp, pp, pp, pp, pp, pp]
+        L.ref_model_destroy.argtypes = [C.c_void_p]
+        L.ref_time_add.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+        L.ref_time_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.ref_forward_taps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, pp]
+        L.ref_conv_layer.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_size_t]
+        L.ref_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.ref_sign_project.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ref_observe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_philox4x32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_cexp.restype = C.c_float
+        L.ref_cexp.argtypes = [C.c_float]
+        L.ref_silu.restype = C.c_float
+        L.ref_silu.argtypes = [C.c_float]
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _ptr_array(arrs):
+    t = (C.c_void_p * len(arrs))()
+    for i, a in enumerate(arrs):
+        t[i] = None if a is None else a.ctypes.data
+    return C.cast(t, C.POINTER(C.c_void_p))
+
+
+class RefModel:
+    """C-oracle UNet built from a ``UNetSpec``-like object (``convs``, ``dense`` lists)."""
+
+    def __init__(self, spec, quant_bf16: bool = False):
+        self.spec = spec
+        self.channels = spec.channels
+        self.filters = spec.base_filters
+        self._keep = []
+
+        def f32(a):
+            a = np.ascontiguousarray(a, np.float32)
+            self._keep.append(a)
+            return a
+
+        cw = [f32(c.kernel.reshape(-1, c.kernel.shape[2], c.kernel.shape[3])) for c in spec.convs]
+        cb = [f32(c.bias) for c in spec.convs]
+        bs = [None if c.bn_scale is None else f32(c.bn_scale) for c in spec.convs]
+        bh = [None if c.bn_shift is None else f32(c.bn_shift) for c in spec.convs]
+        dw = [f32(d.kernel) for d in spec.dense]
+        db = [f32(d.bias) for d in spec.dense]
+        self._h = lib().ref_model_create(spec.channels, spec.base_filters, int(spec.batchnorm), int(quant_bf16),
+                                         _ptr_array(cw), _ptr_array(cb), _ptr_array(bs), _ptr_array(bh),
+                                         _ptr_array(dw), _ptr_array(db))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _LIB is not None:
+            _LIB.ref_model_destroy(h)
+
+    def time_add(self, t_norm: float) -> np.ndarray:
+        out = np.empty(4 * self.filters, np.float32)
+        lib().ref_time_add(self._h, np.float32(t_norm), _ptr(out))
+        return out
+
+    def time_table(self, T: int) -> np.ndarray:
+        out = np.empty((T, 4 * self.filters), np.float32)
+        lib().ref_time_table(self._h, T, _ptr(out))
+        return out
+
+    def layer_shapes(self, H, W):
+        f, c = self.filters, self.channels
+        hp, wp = H + (4 - H % 4) % 4, W + (4 - W % 4) % 4
+        return [(hp, wp, f), (hp, wp, f), (hp // 2, wp // 2, 2 * f), (hp // 2, wp // 2, 2 * f),
+                (hp // 4, wp // 4, 4 * f), (hp // 4, wp // 4, 4 * f), (hp // 2, wp // 2, 2 * f),
+                (hp // 2, wp // 2, 2 * f), (hp, wp, f), (hp, wp, f), (hp, wp, c)]
+
+    def forward(self, x: np.ndarray, t_norm: float, taps: bool = False):
+        """x (B,H,W,C) float32 -> score (B,H,W,C); with taps=True also the 11 layer outputs."""
+        x = np.ascontiguousarray(x, np.float32)
+        B, H, W, _ = x.shape
+        tadd = self.time_add(t_norm)
+        score = np.empty_like(x)
+        if not taps:
+            lib().ref_forward(self._h, _ptr(x), _ptr(tadd), _ptr(score), B, H, W)
+            return score
+        outs = [np.empty((B,) + s, np.float32) for s in self.layer_shapes(H, W)]
+        lib().ref_forward_taps(self._h, _ptr(x), _ptr(tadd), _ptr(score), B, H, W, _ptr_array(outs))
+        return score, outs
+
+    def sample(self, x_T: np.ndarray, betas: np.ndarray, T: int, noise_z=None, record_scores=False):
+        """Reverse schedule from x_T; noise_z (T, B,H,W,C) standard normals indexed by t, or None."""
+        x = np.array(x_T, np.float32, order="C")
+        B, H, W, _ = x.shape
+        betas = np.ascontiguousarray(betas, np.float32)
+        z = None if noise_z is None else np.ascontiguousarray(noise_z, np.float32)
+        if z is not None:
+            assert z.shape == (T,) + x.shape
+        scores = np.empty((T,) + x.shape, np.float32) if record_scores else None
+        lib().ref_sample(self._h, _ptr(x), _ptr(betas), T, _ptr(z), B, H, W, _ptr(scores))
+        return (x, scores) if record_scores else x
+
+
+def update(x, score, z, beta):
+    x = np.array(x, np.float32, order="C")
+    score = np.ascontiguousarray(score, np.float32)
+    z = None if z is None else np.ascontiguousarray(z, np.float32)
+    lib().ref_update(_ptr(x), _ptr(score), _ptr(z), np.float32(beta), x.size)
+    return x
+
+
+def sign_project(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(x.shape, np.int8)
+    lib().ref_sign_project(_ptr(x), _ptr(out), x.size)
+    return out
+
+
+def observe(spins: np.ndarray):
+    """spins (B,L,L) int8 -> (M, S) int64 per lattice."""
+    spins = np.ascontiguousarray(spins, np.int8)
+    B, L, _ = spins.shape
+    M = np.empty(B, np.int64)
+    S = np.empty(B, np.int64)
+    lib().ref_observe(_ptr(spins), B, L, _ptr(M), _ptr(S))
+    return M, S
+
+
+def philox4x32(counter, key) -> np.ndarray:
+    c = np.asarray(counter, np.uint32)
+    k = np.asarray(key, np.uint32)
+    out = np.empty(4, np.uint32)
+    lib().ref_philox4x32(_ptr(c), _ptr(k), _ptr(out))
+    return out
+
+
+def beta_schedule(T: int = 1000) -> np.ndarray:
+    """float32(linspace(1e-4, 0.02, T)) (b_diffusion_model_unet_2d_ising.py:168-172)."""
+    return np.linspace(1e-4, 0.02, T).astype(np.float32)

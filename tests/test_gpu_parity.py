@@ -1,0 +1,252 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle.
+
+Bars: float32 mode is BIT-EXACT against the C oracle (same canonical summation order and
+elementary functions); bf16 mode is within a stated relative-L2 tolerance.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BF16_LAYER_TOL = 1.5e-2   # rel-L2 per layer vs the oracle that rounds to bf16 at the same points
+BF16_SCORE_TOL = 2e-2    # rel-L2 of the score vs the float32 oracle
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def ising_like(rng, B, H, W, t, T=1000):
+    """x_t = sqrt(abar_t) x0 + sqrt(1-abar_t) eps for mostly-aligned ±1 lattices."""
+    x0 = np.ones((B, H, W, 1), np.float32)
+    x0[rng.random((B, H, W, 1)) < 0.045] = -1
+    x0 *= rng.choice([-1, 1], size=(B, 1, 1, 1)).astype(np.float32)
+    ab = np.cumprod(1 - np.linspace(1e-4, 0.02, T))[t]
+    eps = rng.standard_normal(x0.shape).astype(np.float32)
+    return (np.sqrt(ab) * x0 + np.sqrt(1 - ab) * eps).astype(np.float32)
+
+
+def test_time_table_bit_exact(gpu_real, ref_real):
+    got = gpu_real.time_table(1000)
+    want = ref_real.time_table(1000)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("B,H,W,t", [(4, 20, 20, 500), (2, 32, 32, 900), (3, 18, 22, 100), (1, 4, 4, 0), (5, 20, 20, 999)])
+def test_forward_fp32_bit_exact(gpu_real, ref_real, B, H, W, t):
+    rng = np.random.default_rng(B * 1000 + H)
+    x = ising_like(rng, B, H, W, t)
+    tn = np.float32(t) / np.float32(1000)
+    want, taps = ref_real.forward(x, tn, taps=True)
+    got, gtaps = gpu_real.forward_taps(x, tn, precision="fp32")
+    for i in range(10):
+        g = gtaps[i].cpu().numpy()
+        assert g.shape == taps[i].shape
+        bad = np.count_nonzero(g.view(np.uint32) != taps[i].view(np.uint32))
+        assert bad == 0, f"layer {i}: {bad} of {g.size} elements differ, max abs {np.abs(g - taps[i]).max()}"
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("B,H,W,t", [(4, 20, 20, 500), (2, 32, 32, 900), (2, 18, 22, 700)])
+def test_forward_bf16_tolerance(gpu_real, real_spec, ref_real, B, H, W, t):
+    from oracle import ref_cpu
+    refq = ref_cpu.RefModel(real_spec, quant_bf16=True)
+    rng = np.random.default_rng(7)
+    x = ising_like(rng, B, H, W, t)
+    tn = np.float32(t) / np.float32(1000)
+    want_q, taps_q = refq.forward(x, tn, taps=True)
+    want = ref_real.forward(x, tn)
+    got, gtaps = gpu_real.forward_taps(x, tn, precision="bf16")
+    for i in range(10):
+        e = rel_l2(gtaps[i].cpu().numpy(), taps_q[i])
+        assert e < BF16_LAYER_TOL, f"layer {i}: rel-L2 {e}"
+    eq, ef = rel_l2(got.cpu().numpy(), want_q), rel_l2(got.cpu().numpy(), want)
+    assert eq < BF16_LAYER_TOL, eq
+    assert ef < BF16_SCORE_TOL, ef
+
+
+def test_call_and_predict_interfaces(gpu_real, ref_real):
+    import torch
+    rng = np.random.default_rng(3)
+    x = ising_like(rng, 6, 20, 20, 800)
+    tn = np.full((6, 1), np.float32(800) / np.float32(1000), np.float32)
+    want = ref_real.forward(x, tn[0, 0])
+    out_np = gpu_real([x, tn])
+    assert isinstance(out_np, np.ndarray)
+    assert np.array_equal(out_np, want)
+    out_t = gpu_real([torch.from_numpy(x).cuda(), torch.from_numpy(tn).cuda()])
+    assert isinstance(out_t, torch.Tensor) and out_t.is_cuda and np.array_equal(out_t.cpu().numpy(), want)
+    assert np.array_equal(gpu_real.predict([x, tn], batch_size=4), want)
+    with pytest.raises(ValueError):
+        gpu_real([x, np.linspace(0, 1, 6, dtype=np.float32)[:, None]])
+    with pytest.raises(ValueError):
+        gpu_real([x[..., 0], tn])
+    assert gpu_real([x[:0], tn[:1]]).shape == (0, 20, 20, 1)
+
+
+def test_sampler_fp32_injected_noise_bit_exact(gpu_real, ref_real):
+    """Deterministic mode, free running for the full schedule: per-step scores, every state of the
+    trajectory and the final spins must equal the oracle's bit for bit."""
+    from isingdiff.sampler import beta_schedule, diffusion_backward
+    from isingdiff.observables import sign_project, observe
+    from oracle import ref_cpu
+    import torch
+    B, L, T = 4, 20, 1000
+    rs = np.random.RandomState(0)
+    x_T = rs.standard_normal((B, L, L, 1)).astype(np.float32)
+    z = rs.standard_normal((T, B, L, L, 1)).astype(np.float32)
+    betas = beta_schedule(T)
+    want_x, want_scores = ref_real.sample(x_T, betas, T, noise_z=z, record_scores=True)
+    traj, scores = diffusion_backward(x_T, betas, gpu_real, T, noise=z, precision="fp32", return_scores=True)
+    assert traj.shape == (T + 1, B, L, L, 1)
+    assert np.array_equal(traj[T], x_T)
+    for t in (999, 900, 500, 100, 0):
+        assert np.array_equal(scores[t].view(np.uint32), want_scores[t].view(np.uint32)), f"score at t={t}"
+    assert np.array_equal(scores.view(np.uint32), want_scores.view(np.uint32))
+    assert np.array_equal(traj[0].view(np.uint32), want_x.view(np.uint32))
+    assert np.isfinite(traj[0]).all()
+    spins = sign_project(torch.from_numpy(traj[0]).cuda()).cpu().numpy()
+    want_spins = ref_cpu.sign_project(want_x)
+    assert np.array_equal(spins, want_spins)
+    obs = observe(torch.from_numpy(spins[..., 0]).cuda())
+    M, S = ref_cpu.observe(want_spins[..., 0])
+    assert np.array_equal(obs.M.cpu().numpy(), M) and np.array_equal(obs.S.cpu().numpy(), S)
+
+
+def test_sampler_matches_golden(gpu_real):
+    """Committed fixture (tests/golden/make_golden.py): B=4, L=20, RandomState(0) noise."""
+    import os
+    from isingdiff.sampler import beta_schedule, diffusion_backward
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "realspace_B4_L20_seed0.npz"))
+    B, L, T = 4, 20, 1000
+    rs = np.random.RandomState(0)
+    x_T = rs.standard_normal((B, L, L, 1)).astype(np.float32)
+    z = rs.standard_normal((T, B, L, L, 1)).astype(np.float32)
+    traj, scores = diffusion_backward(x_T, beta_schedule(T), gpu_real, T, noise=z, precision="fp32", return_scores=True)
+    for t in (999, 900, 500, 0):
+        assert np.array_equal(scores[t].reshape(B, -1), g[f"score_t{t}"])
+    spins = np.where(traj[0] > 0, 1, -1).astype(np.int8).reshape(B, L, L)
+    assert np.array_equal(spins, g["spins"])
+
+
+def test_sampler_bf16_teacher_forced(gpu_real, ref_real):
+    """bf16 scores along the oracle's own float32 trajectory (teacher forcing): rel-L2 per step."""
+    from isingdiff.sampler import beta_schedule
+    from oracle import ref_cpu
+    B, L, T = 4, 20, 1000
+    rs = np.random.RandomState(1)
+    x = rs.standard_normal((B, L, L, 1)).astype(np.float32)
+    betas = beta_schedule(T)
+    worst = 0.0
+    for t in range(T - 1, -1, -1):
+        tn = np.float32(t) / np.float32(T)
+        s_ref = ref_real.forward(x, tn)
+        if t % 50 == 0 or t == T - 1:
+            s_gpu = gpu_real([x, tn], precision="bf16")
+            worst = max(worst, rel_l2(s_gpu, s_ref))
+        x = ref_cpu.update(x, s_ref, rs.standard_normal(x.shape).astype(np.float32), betas[t])
+    assert worst < BF16_SCORE_TOL, worst
+
+
+def test_update_bit_exact():
+    import ctypes as C
+    import torch
+    from isingdiff import _lib
+    from oracle import ref_cpu
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 400, 4099):
+        x = (rng.standard_normal(n) * 1e3).astype(np.float32)
+        s = (rng.standard_normal(n) * 1e2).astype(np.float32)
+        z = rng.standard_normal(n).astype(np.float32)
+        for beta in [np.float32(1e-4), np.float32(0.02), np.float32(0.0123456)] + list(np.linspace(1e-4, 0.02, 1000).astype(np.float32)[::37]):
+            want = ref_cpu.update(x, s, z, beta)
+            xd, sd, zd = (torch.from_numpy(a).cuda() for a in (x.copy(), s, z))
+            _lib.check(_lib.load().idm_update(0, xd.data_ptr(), sd.data_ptr(), zd.data_ptr(), C.c_float(beta), n, None))
+            torch.cuda.synchronize()
+            assert np.array_equal(xd.cpu().numpy().view(np.uint32), want.view(np.uint32))
+            want0 = ref_cpu.update(x, s, None, beta)
+            xd = torch.from_numpy(x.copy()).cuda()
+            _lib.check(_lib.load().idm_update(0, xd.data_ptr(), sd.data_ptr(), None, C.c_float(beta), n, None))
+            torch.cuda.synchronize()
+            assert np.array_equal(xd.cpu().numpy().view(np.uint32), want0.view(np.uint32))
+
+
+def _philox_normals_cpu(seed, lattice, elems, t):
+    from oracle import ref_cpu
+    out = np.empty(((elems + 3) // 4) * 4, np.float64)
+    for q in range((elems + 3) // 4):
+        r = ref_cpu.philox4x32([q, lattice & 0xFFFFFFFF, lattice >> 32, t], [seed & 0xFFFFFFFF, seed >> 32])
+        u = ((r >> 8).astype(np.float64) + 0.5) * 2.0 ** -24
+        m0, m1 = np.sqrt(-2 * np.log(u[0])), np.sqrt(-2 * np.log(u[2]))
+        out[4 * q:4 * q + 4] = [m0 * np.cos(2 * np.pi * u[1]), m0 * np.sin(2 * np.pi * u[1]),
+                                m1 * np.cos(2 * np.pi * u[3]), m1 * np.sin(2 * np.pi * u[3])]
+    return out[:elems]
+
+
+def test_philox_stream_matches_counter_definition():
+    """Noise depends only on (seed, global lattice, element, t): check against the C oracle's
+    Philox4x32-10 + Box-Muller in float64, and check shard independence."""
+    import torch
+    from isingdiff import _lib
+    seed, elems, t = 0x1234567890ABCDEF, 401, 17
+    out = torch.empty((5, elems), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.load().idm_philox_normal(0, out.data_ptr(), 5, elems, seed, 2 ** 33 + 3, t, None))
+    part = torch.empty((2, elems), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.load().idm_philox_normal(0, part.data_ptr(), 2, elems, seed, 2 ** 33 + 5, t, None))
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert np.array_equal(o[2:4], part.cpu().numpy())
+    for b in (0, 4):
+        want = _philox_normals_cpu(seed, 2 ** 33 + 3 + b, elems, t)
+        assert np.allclose(o[b], want, atol=2e-5, rtol=1e-5)
+    big = torch.empty((4096, 400), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.load().idm_philox_normal(0, big.data_ptr(), 4096, 400, 42, 0, 3, None))
+    v = big.double()
+    assert abs(float(v.mean())) < 4e-3 and abs(float(v.var()) - 1) < 6e-3
+    assert abs(float((v ** 4).mean()) - 3) < 0.05
+
+
+@pytest.mark.parametrize("L", [4, 20, 32, 64, 128])
+def test_observables_exact(L):
+    import torch
+    from isingdiff.observables import observe
+    from oracle import ref_cpu
+    rng = np.random.default_rng(L)
+    B = 37
+    spins = rng.choice(np.array([-1, 1], np.int8), size=(B, L, L))
+    spins[0] = 1
+    spins[1] = -1
+    yy, xx = np.meshgrid(np.arange(L), np.arange(L), indexing="ij")
+    spins[2] = np.where((yy + xx) % 2 == 0, 1, -1)
+    obs = observe(torch.from_numpy(spins).cuda())
+    M, S = ref_cpu.observe(spins)
+    assert np.array_equal(obs.M.cpu().numpy(), M) and np.array_equal(obs.S.cpu().numpy(), S)
+    assert M[0] == L * L and S[0] == 2 * L * L and S[2] == -2 * L * L
+    assert obs.energy(1.0, 0.0)[0] == -2 * L * L
+    hM = np.bincount((M + L * L) // 2, minlength=L * L + 1)
+    hS = np.bincount((S + 2 * L * L) // 2, minlength=2 * L * L + 1)
+    assert np.array_equal(obs.hist_M.cpu().numpy(), hM) and np.array_equal(obs.hist_S.cpu().numpy(), hS)
+    mom = obs.moments.cpu().numpy()
+    assert list(mom) == [B, M.sum(), np.abs(M).sum(), (M ** 2).sum(), S.sum(), (S ** 2).sum()]
+    # the reference's numpy formulas
+    s = spins.astype(np.float64)
+    e_np = -(np.sum(s * np.roll(s, -1, 1), (1, 2)) + np.sum(s * np.roll(s, -1, 2), (1, 2)))
+    assert np.array_equal(obs.energy(1.0, 0.0), e_np)
+    assert np.allclose(obs.magnetization(), s.mean((1, 2)))
+
+
+def test_sample_philox_shard_independent(gpu_real):
+    """sample() on [0,6) equals sample() on [0,3) and [3,6) with global indices (fp32, short schedule)."""
+    from isingdiff.sampler import sample, beta_schedule
+    T = 20
+    betas = beta_schedule(1000)[:T]
+    full = sample(gpu_real, 6, 20, T=T, betas=betas, seed=9, precision="fp32", keep_state=True)
+    a = sample(gpu_real, 3, 20, T=T, betas=betas, seed=9, precision="fp32", keep_state=True)
+    b = sample(gpu_real, 3, 20, T=T, betas=betas, seed=9, precision="fp32", keep_state=True, first_global_index=3)
+    import torch
+    assert torch.equal(full.x_final[:3], a.x_final) and torch.equal(full.x_final[3:], b.x_final)
+    assert torch.equal(full.spins[3:], b.spins)
+    c = sample(gpu_real, 6, 20, T=T, betas=betas, seed=9, precision="fp32", keep_state=True, chunk=4)
+    assert torch.equal(full.x_final, c.x_final)
+    assert int(full.observables.moments[0]) == 6

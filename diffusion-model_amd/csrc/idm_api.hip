@@ -94,6 +94,12 @@ struct idm_model {
     char *ws = nullptr;                    // activation workspace
     size_t ws_bytes = 0;
     std::vector<void *> owned;
+    // profiling (idm_profile_begin/end)
+    bool profiling = false;
+    struct Span { int cls; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    std::vector<idm_profile_entry> classes;
+    std::vector<hipEvent_t> event_pool;
 };
 
 namespace {
@@ -148,6 +154,41 @@ int ensure_ws(idm_model *m, size_t bytes)
     return IDM_OK;
 }
 
+int prof_class(idm_model *m, const char *name)
+{
+    for (size_t i = 0; i < m->classes.size(); ++i)
+        if (!strcmp(m->classes[i].name, name)) return (int)i;
+    idm_profile_entry e;
+    memset(&e, 0, sizeof(e));
+    snprintf(e.name, sizeof(e.name), "%s", name);
+    m->classes.push_back(e);
+    return (int)m->classes.size() - 1;
+}
+
+hipEvent_t prof_event(idm_model *m)
+{
+    if (!m->event_pool.empty()) { hipEvent_t e = m->event_pool.back(); m->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// Runs `launch` and, when profiling, brackets it with events on stream s.
+template <typename F>
+void timed(idm_model *m, const char *name, double flop, double bytes, hipStream_t s, F &&launch)
+{
+    if (!m->profiling) { launch(); return; }
+    const int cls = prof_class(m, name);
+    m->classes[cls].launches += 1;
+    m->classes[cls].flop += flop;
+    m->classes[cls].bytes += bytes;
+    idm_model::Span sp{cls, prof_event(m), prof_event(m)};
+    (void)hipEventRecord(sp.a, s);
+    launch();
+    (void)hipEventRecord(sp.b, s);
+    m->spans.push_back(sp);
+}
+
 int64_t auto_chunk(const Plan &p, int64_t B)
 {
     const size_t budget = (size_t)6 << 30;  // keep the activation workspace around 6 GiB
@@ -168,7 +209,10 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
     const bool bf = precision == IDM_BF16;
     const int F = m->F, Hp = p.Hp, Wp = p.Wp;
 
-    launch_conv_first(x, Bc, p.H, p.W, Hp, Wp, m->C, m->w_first, m->bias[0], m->scale[0], m->shift[0], a0, F, bf, s);
+    const double npx = (double)Bc * Hp * Wp;
+    timed(m, "conv_first", 2.0 * 9 * m->C * F * npx, (double)Bc * p.H * p.W * m->C * 4 + npx * F * p.es, s, [&] {
+        launch_conv_first(x, Bc, p.H, p.W, Hp, Wp, m->C, m->w_first, m->bias[0], m->scale[0], m->shift[0], a0, F, bf, s);
+    });
 
     auto conv = [&](int layer, const void *in0, const void *in1, int C0, int C1, int H, int W, int mode, void *out,
                     const float *ta, bool out_f32) {
@@ -177,7 +221,12 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
         a.wpack = bf ? m->wpack_bf16[layer] : m->wpack_f32[layer];
         a.bias = m->bias[layer]; a.scale = m->scale[layer]; a.shift = m->shift[layer]; a.tadd = ta;
         a.out = out; a.Cout = m->cout[layer]; a.mode = mode; a.silu = 1; a.out_f32 = out_f32 ? 1 : 0;
-        if (bf) launch_conv_bf16(a, s); else launch_conv_f32(a, s);
+        char name[32];
+        snprintf(name, sizeof(name), "conv%d_%s", layer, bf ? "bf16" : "f32");
+        const double px = (double)Bc * H * W;
+        const double in_px = mode == CONV_POOL ? 4.0 * C0 : (mode == CONV_UPCAT ? 0.25 * C0 + C1 : (double)C0);
+        timed(m, name, 2.0 * 9 * (C0 + C1) * a.Cout * px, px * (in_px * p.es + a.Cout * (out_f32 ? 4 : p.es)), s,
+              [&] { if (bf) launch_conv_bf16(a, s); else launch_conv_f32(a, s); });
     };
     conv(1, a0, nullptr, F, 0, Hp, Wp, CONV_PLAIN, s1, nullptr, false);
     conv(2, s1, nullptr, F, 0, Hp / 2, Wp / 2, CONV_POOL, a2, nullptr, false);
@@ -188,7 +237,8 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
     conv(7, a6, nullptr, 2 * F, 0, Hp / 2, Wp / 2, CONV_PLAIN, a7, nullptr, false);
     conv(8, a7, s1, 2 * F, F, Hp, Wp, CONV_UPCAT, a8, nullptr, false);
     conv(9, a8, nullptr, F, 0, Hp, Wp, CONV_PLAIN, a9, nullptr, true);
-    launch_head(a9, Bc, p.H, p.W, Hp, Wp, F, m->C, m->w_head, m->bias[10], score, s);
+    timed(m, "head", 2.0 * F * m->C * Bc * p.H * p.W, (double)Bc * p.H * p.W * (F * 4 + m->C * 4), s,
+          [&] { launch_head(a9, Bc, p.H, p.W, Hp, Wp, F, m->C, m->w_head, m->bias[10], score, s); });
 
     if (taps) {
         const size_t n1 = (size_t)Hp * Wp, n2 = n1 / 4, n4 = n1 / 16;
@@ -290,6 +340,8 @@ int idm_model_destroy(idm_model *m)
     for (void *p : m->owned) (void)hipFree(p);
     if (m->ttable) (void)hipFree(m->ttable);
     if (m->ws) (void)hipFree(m->ws);
+    for (auto &sp : m->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (hipEvent_t e : m->event_pool) (void)hipEventDestroy(e);
     delete m;
     return IDM_OK;
 }
@@ -382,7 +434,9 @@ int idm_sample(idm_model *m, const idm_sample_cfg *cfg, float *x_dev, const floa
             if (rc != IDM_OK) return rc;
             ph.t = t;
             const float *z = noise_dev ? noise_dev + (size_t)t * total + b0 * elems : nullptr;
-            launch_update(x, score, z, cfg->betas_host[t], bc, (int64_t)elems, cfg->add_noise != 0, ph, s);
+            timed(m, "update", 0.0, (double)bc * elems * (z ? 16 : 12), s, [&] {
+                launch_update(x, score, z, cfg->betas_host[t], bc, (int64_t)elems, cfg->add_noise != 0, ph, s);
+            });
             if (traj_dev)
                 HIPCHK(hipMemcpyAsync(traj_dev + (size_t)t * total + b0 * elems, x, bc * elems * 4, hipMemcpyDeviceToDevice, s));
         }
@@ -430,6 +484,37 @@ int idm_observe(int device, const int8_t *spins_dev, int64_t B, int L, int32_t *
     HIPCHK(hipSetDevice(device));
     launch_observe(spins_dev, B, L, M_dev, S_dev, hist_M_dev, hist_S_dev, moments_dev, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
+    return IDM_OK;
+}
+
+int idm_profile_begin(idm_model *m)
+{
+    if (!m) return fail(IDM_ERR_INVALID, "null model");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipDeviceSynchronize());
+    for (auto &sp : m->spans) { m->event_pool.push_back(sp.a); m->event_pool.push_back(sp.b); }
+    m->spans.clear();
+    m->classes.clear();
+    m->profiling = true;
+    return IDM_OK;
+}
+
+int idm_profile_end(idm_model *m, idm_profile_entry *entries, int cap, int *n)
+{
+    if (!m || !n) return fail(IDM_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipDeviceSynchronize());
+    m->profiling = false;
+    for (auto &sp : m->spans) {
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, sp.a, sp.b));
+        m->classes[sp.cls].ms += ms;
+        m->event_pool.push_back(sp.a);
+        m->event_pool.push_back(sp.b);
+    }
+    m->spans.clear();
+    *n = (int)m->classes.size();
+    for (int i = 0; i < *n && i < cap && entries; ++i) entries[i] = m->classes[i];
     return IDM_OK;
 }
 

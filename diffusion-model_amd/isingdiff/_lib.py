@@ -39,6 +39,11 @@ class SampleCfg(C.Structure):
     ]
 
 
+class ProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_int64), ("ms", C.c_double), ("flop", C.c_double),
+                ("bytes", C.c_double)]
+
+
 # name -> (restype, argtypes); every symbol include/isingdiff.h declares
 SIGNATURES = {
     "idm_abi_version": (C.c_int, []),
@@ -56,6 +61,8 @@ SIGNATURES = {
     "idm_sign_project": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "idm_observe": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_void_p]),
+    "idm_profile_begin": (C.c_int, [C.c_void_p]),
+    "idm_profile_end": (C.c_int, [C.c_void_p, C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),
 }
 
 _lib = None
@@ -68,6 +75,9 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise IdmError(f"{LIB_PATH} not found: build it with `make -C diffusion-model_amd/csrc` "
                            "(there is no CPU fallback)")
+        # PyTorch bundles its own HIP runtime (same SONAME as /opt/rocm's).  Import it first so that
+        # this library binds to the runtime that owns torch's device pointers and streams.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -157,6 +157,20 @@ class ScoreModel:
                                                     C.cast(arr, C.POINTER(C.c_void_p)), _stream_ptr(self.device)))
         return score, taps
 
+    def profile_begin(self):
+        """Start per-kernel event timing of this model's launches (see idm_profile_begin)."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().idm_profile_begin(self.handle))
+
+    def profile_end(self):
+        """Stop timing; returns [{name, launches, ms, flop, bytes}] per kernel class."""
+        ents = (_lib.ProfileEntry * 32)()
+        n = C.c_int(0)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().idm_profile_end(self.handle, ents, 32, C.byref(n)))
+        return [dict(name=e.name.decode(), launches=e.launches, ms=e.ms, flop=e.flop, bytes=e.bytes)
+                for e in ents[:min(n.value, 32)]]
+
     def time_table(self, T: int) -> np.ndarray:
         out = np.empty((T, 4 * self.spec.base_filters), np.float32)
         with torch.cuda.device(self.device):

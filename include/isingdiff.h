@@ -137,6 +137,23 @@ int idm_observe(int device, const int8_t *spins_dev, int64_t B, int L, int32_t *
                 unsigned long long *hist_M_dev, unsigned long long *hist_S_dev, long long *moments_dev,
                 void *stream);
 
+/* Per-kernel timing for roofline accounting (no counterpart in the reference).  Between
+ * idm_profile_begin and idm_profile_end every kernel launch of idm_forward / idm_sample on this
+ * handle is bracketed by HIP events recorded on the call's own stream.  idm_profile_end
+ * synchronises the device and fills up to `cap` entries (one per kernel class, in launch order of
+ * first use); *n receives the number of classes.  flop / bytes are the ALGORITHMIC work of the
+ * launches (2*MACs of the convolutions; bytes each launch must read and write once). */
+typedef struct {
+    char name[32];
+    int64_t launches;
+    double ms;        /* sum of event-timed durations */
+    double flop;
+    double bytes;
+} idm_profile_entry;
+
+int idm_profile_begin(idm_model *m);
+int idm_profile_end(idm_model *m, idm_profile_entry *entries, int cap, int *n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,18 @@ std::vector<float> pack_weights_f32(const float *w, int cin, int cout)
     return p;
 }
 
+// Layer 0 (Cin = 1) as a single A fragment: lane l holds W0[tap = 8*(l>>5) + j][cout = l&31], zero for tap > 8.
+std::vector<uint16_t> pack_first_bf16(const float *w, int cout)
+{
+    std::vector<uint16_t> p(64 * 8, 0);
+    for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * (l >> 5) + j, co = l & 31;
+            if (k < 9 && co < cout) p[l * 8 + j] = bf16_bits(w[(size_t)k * cout + co]);
+        }
+    return p;
+}
+
 }  // namespace
 
 struct idm_model {
@@ -79,6 +91,8 @@ struct idm_model {
     int C = 1, F = 32;
     bool bn = false;
     int cin[IDM_NCONV], cout[IDM_NCONV];
+    bool use_fused = true;                 // bf16: fused band kernels where they fit
+    void *w_first_pack = nullptr;          // layer 0 as one bf16 MFMA A fragment (C == 1)
     float *w_first = nullptr;              // (9, C, F) float32
     float *w_head = nullptr;               // (F, C) float32
     void *wpack_f32[IDM_NCONV] = {};       // layers 1..9
@@ -117,7 +131,35 @@ struct Plan {
     int H, W, Hp, Wp;
     size_t es;  // activation element size
     size_t off_a0, off_s1, off_a2, off_s2, off_a4, off_a5, off_a6, off_a7, off_a8, off_a9, off_score, per_lattice;
+    bool fused;          // bf16 fused band kernels usable for this shape
+    int R[5];            // band rows per fused kernel
 };
+
+// Everything the last fused kernel needs to apply the reverse-diffusion update in place.
+struct StepCtx {
+    bool do_update = false;
+    float *x = nullptr;
+    const float *noise = nullptr;
+    float beta = 0.0f;
+    bool add_noise = false;
+    PhiloxArgs ph = {0, 0, 0};
+};
+
+// Largest band height whose LDS footprint leaves room for two workgroups per CU.
+int pick_band_rows(int kind, int H, int W)
+{
+    const int limit = 78 * 1024;
+    const int cand[5] = {H, 16, 8, 4, 2};
+    for (int i = 0; i < 5; ++i) {
+        const int R = cand[i];
+        if (R > H || (i > 0 && R >= H)) continue;
+        if ((R & 1) && kind != FK_M2) continue;
+        int in = 0, mid = 0;
+        fused_lds_bytes(kind, W, R, &in, &mid);
+        if (in + mid <= limit) return R;
+    }
+    return 0;
+}
 
 Plan make_plan(const idm_model *m, int H, int W, int precision)
 {
@@ -141,6 +183,14 @@ Plan make_plan(const idm_model *m, int H, int W, int precision)
     p.off_a9 = take(n1 * F * 4);
     p.off_score = take((size_t)H * W * m->C * 4);
     p.per_lattice = o;
+    p.fused = precision == IDM_BF16 && m->C == 1 && m->use_fused && m->w_first_pack != nullptr;
+    if (p.fused) {
+        const int hh[5] = {p.Hp, p.Hp / 2, p.Hp / 4, p.Hp / 2, p.Hp}, ww[5] = {p.Wp, p.Wp / 2, p.Wp / 4, p.Wp / 2, p.Wp};
+        for (int k = 0; k < 5; ++k) {
+            p.R[k] = pick_band_rows(k, hh[k], ww[k]);
+            if (p.R[k] == 0) p.fused = false;
+        }
+    }
     return p;
 }
 
@@ -152,6 +202,16 @@ int ensure_ws(idm_model *m, size_t bytes)
     if (e != hipSuccess) return fail(IDM_ERR_NOMEM, "workspace allocation of " + std::to_string(bytes) + " bytes failed");
     m->ws_bytes = bytes;
     return IDM_OK;
+}
+
+// c1 = 1 + 0.5*beta and sd = sqrt(beta), each operation rounded to float32 on the host.
+void step_constants(float beta, float *c1, float *sd)
+{
+    volatile float half_beta = 0.5f * beta;
+    volatile float one_plus = 1.0f + half_beta;
+    volatile float root = sqrtf(beta);
+    *c1 = one_plus;
+    *sd = root;
 }
 
 int prof_class(idm_model *m, const char *name)
@@ -198,6 +258,91 @@ int64_t auto_chunk(const Plan &p, int64_t B)
 
 // Forward for `Bc` lattices whose workspace starts at m->ws.  Buffers of one kind are contiguous
 // over the chunk: base + off_kind*Bc.
+int forward_fused(idm_model *m, const Plan &p, const float *x, const float *tadd, float *score, int64_t Bc,
+                  const StepCtx &ctx, float *const *taps, int64_t tap_b0, hipStream_t s)
+{
+    char *ws = m->ws;
+    auto buf = [&](size_t off) { return (void *)(ws + off * (size_t)Bc); };
+    void *s1 = buf(p.off_s1), *p1 = buf(p.off_a0), *s2 = buf(p.off_s2), *p2 = buf(p.off_a2), *a5 = buf(p.off_a5),
+         *a7 = buf(p.off_a7);
+    const int F = m->F, Hp = p.Hp, Wp = p.Wp;
+    const double n1 = (double)Bc * Hp * Wp, n2 = n1 / 4, n4 = n1 / 16;
+    auto run = [&](int kind, const char *name, FusedArgs &a, int H, int W, double flop, double bytes) -> int {
+        a.H = H; a.W = W; a.R = p.R[kind]; a.nbands = (H + a.R - 1) / a.R;
+        a.Hx = p.H; a.Wx = p.W;
+        fused_lds_bytes(kind, W, a.R, &a.lds_in_bytes, &a.lds_mid_bytes);
+        hipError_t e = hipSuccess;
+        timed(m, name, flop, bytes, s, [&] { e = launch_fused(kind, a, Bc, s); });
+        if (e != hipSuccess) return fail(IDM_ERR_HIP, std::string("launch ") + name + ": " + hipGetErrorString(e));
+        return IDM_OK;
+    };
+    auto layer = [&](FusedArgs &a, int l1, int l2) {
+        a.w1 = l1 == 0 ? m->w_first_pack : m->wpack_bf16[l1];
+        a.b1 = m->bias[l1]; a.s1 = m->scale[l1]; a.h1 = m->shift[l1];
+        a.w2 = m->wpack_bf16[l2]; a.b2 = m->bias[l2]; a.s2 = m->scale[l2]; a.h2 = m->shift[l2];
+    };
+    int rc;
+    {   // x -> conv0 -> conv1 -> skip1 (+ pooled)
+        FusedArgs a = {};
+        layer(a, 0, 1);
+        a.in_a = x; a.out = s1; a.out_pool = p1;
+        rc = run(FK_A, "fused_A(conv0,1)", a, Hp, Wp, 2.0 * 9 * (F + F * F) * n1, (double)Bc * p.H * p.W * 4 + n1 * F * 2 + n2 * F * 2);
+        if (rc != IDM_OK) return rc;
+    }
+    {   // pooled -> conv2 -> conv3 -> skip2 (+ pooled)
+        FusedArgs a = {};
+        layer(a, 2, 3);
+        a.in_a = p1; a.out = s2; a.out_pool = p2;
+        rc = run(FK_M1, "fused_M1(conv2,3)", a, Hp / 2, Wp / 2, 2.0 * 9 * (F * 2 * F + 4 * F * F) * n2, n2 * F * 2 + n2 * 2 * F * 2 + n4 * 2 * F * 2);
+        if (rc != IDM_OK) return rc;
+    }
+    {   // pooled -> conv4 (+time) -> conv5
+        FusedArgs a = {};
+        layer(a, 4, 5);
+        a.tadd1 = tadd;
+        a.in_a = p2; a.out = a5;
+        rc = run(FK_M2, "fused_M2(conv4,5)", a, Hp / 4, Wp / 4, 2.0 * 9 * (8 * F * F + 16 * F * F) * n4, n4 * 2 * F * 2 + n4 * 4 * F * 2);
+        if (rc != IDM_OK) return rc;
+    }
+    {   // [up(conv5), skip2] -> conv6 -> conv7
+        FusedArgs a = {};
+        layer(a, 6, 7);
+        a.in_a = a5; a.in_b = s2; a.out = a7;
+        rc = run(FK_M3, "fused_M3(conv6,7)", a, Hp / 2, Wp / 2, 2.0 * 9 * (12 * F * F + 4 * F * F) * n2, n4 * 4 * F * 2 + n2 * 2 * F * 2 + n2 * 2 * F * 2);
+        if (rc != IDM_OK) return rc;
+    }
+    {   // [up(conv7), skip1] -> conv8 -> conv9 -> head -> (update)
+        FusedArgs a = {};
+        layer(a, 8, 9);
+        a.in_a = a7; a.in_b = s1;
+        a.w_head = m->w_head; a.b_head = m->bias[10];
+        a.score_out = score;
+        a.do_update = ctx.do_update ? 1 : 0;
+        a.x = ctx.x; a.noise = ctx.noise; a.add_noise = ctx.add_noise ? 1 : 0; a.ph = ctx.ph;
+        a.beta = ctx.beta;
+        step_constants(ctx.beta, &a.c1, &a.sd);
+        rc = run(FK_B, "fused_B(conv8,9,head,step)", a, Hp, Wp, 2.0 * 9 * (3 * F * F + F * F) * n1 + 2.0 * F * n1,
+                 n2 * 2 * F * 2 + n1 * F * 2 + (double)Bc * p.H * p.W * 8);
+        if (rc != IDM_OK) return rc;
+    }
+    if (taps) {
+        const size_t c1 = (size_t)Hp * Wp, c2 = c1 / 4, c4 = c1 / 16;
+        const void *src[10] = {nullptr, s1, nullptr, s2, nullptr, a5, nullptr, a7, nullptr, nullptr};
+        const size_t cnt[10] = {c1 * F, c1 * F, c2 * 2 * F, c2 * 2 * F, c4 * 4 * F, c4 * 4 * F, c2 * 2 * F, c2 * 2 * F, c1 * F, c1 * F};
+        for (int i = 0; i < 10; ++i) {
+            if (!taps[i]) continue;
+            float *dst = taps[i] + (size_t)tap_b0 * cnt[i];
+            if (src[i]) launch_cast_bf16_to_f32(src[i], dst, (int64_t)(cnt[i] * Bc), s);
+            else HIPCHK(hipMemsetAsync(dst, 0xFF, cnt[i] * Bc * 4, s));  // NaN pattern: not materialised by the fused path
+        }
+        if (taps[10] && score)
+            HIPCHK(hipMemcpyAsync(taps[10] + (size_t)tap_b0 * p.H * p.W * m->C, score, (size_t)Bc * p.H * p.W * m->C * 4,
+                                  hipMemcpyDeviceToDevice, s));
+    }
+    HIPCHK(hipGetLastError());
+    return IDM_OK;
+}
+
 int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd, float *score, int64_t Bc,
                   int precision, float *const *taps, int64_t tap_b0, hipStream_t s)
 {
@@ -308,7 +453,13 @@ int idm_model_create(idm_model **out, int device, const idm_model_desc *d)
             if (rc == IDM_OK) rc = upload(m, d->bn_shift[i], (size_t)cout[i], &m->shift[i]);
         }
         if (rc != IDM_OK) break;
-        if (i == 0) rc = upload(m, d->conv_w[0], (size_t)9 * c * f, &m->w_first);
+        if (i == 0) {
+            rc = upload(m, d->conv_w[0], (size_t)9 * c * f, &m->w_first);
+            if (rc == IDM_OK && c == 1) {
+                std::vector<uint16_t> pk = pack_first_bf16(d->conv_w[0], f);
+                rc = upload(m, pk.data(), pk.size(), (uint16_t **)&m->w_first_pack);
+            }
+        }
         else if (i == 10) rc = upload(m, d->conv_w[10], (size_t)f * c, &m->w_head);
         else {
             std::vector<uint16_t> pb = pack_weights_bf16(d->conv_w[i], cin[i], cout[i]);
@@ -381,7 +532,10 @@ int idm_forward_taps(idm_model *m, const float *x_dev, float t_norm, float *scor
     const size_t elems = (size_t)H * W * m->C;
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t bc = std::min(chunk, B - b0);
-        rc = forward_chunk(m, p, x_dev + b0 * elems, m->trow, score_dev + b0 * elems, bc, precision, taps_dev, b0, s);
+        if (p.fused)
+            rc = forward_fused(m, p, x_dev + b0 * elems, m->trow, score_dev + b0 * elems, bc, StepCtx(), taps_dev, b0, s);
+        else
+            rc = forward_chunk(m, p, x_dev + b0 * elems, m->trow, score_dev + b0 * elems, bc, precision, taps_dev, b0, s);
         if (rc != IDM_OK) return rc;
     }
     return IDM_OK;
@@ -430,13 +584,21 @@ int idm_sample(idm_model *m, const idm_sample_cfg *cfg, float *x_dev, const floa
             HIPCHK(hipMemcpyAsync(traj_dev + (size_t)T * total + b0 * elems, x, bc * elems * 4, hipMemcpyDeviceToDevice, s));
         for (int t = T - 1; t >= 0; --t) {
             float *score = scores_dev ? scores_dev + (size_t)t * total + b0 * elems : score_ws;
-            rc = forward_chunk(m, p, x, m->ttable + (size_t)t * nf, score, bc, cfg->precision, nullptr, 0, s);
-            if (rc != IDM_OK) return rc;
             ph.t = t;
             const float *z = noise_dev ? noise_dev + (size_t)t * total + b0 * elems : nullptr;
-            timed(m, "update", 0.0, (double)bc * elems * (z ? 16 : 12), s, [&] {
-                launch_update(x, score, z, cfg->betas_host[t], bc, (int64_t)elems, cfg->add_noise != 0, ph, s);
-            });
+            if (p.fused) {
+                StepCtx ctx;
+                ctx.do_update = true; ctx.x = x; ctx.noise = z; ctx.beta = cfg->betas_host[t];
+                ctx.add_noise = cfg->add_noise != 0; ctx.ph = ph;
+                rc = forward_fused(m, p, x, m->ttable + (size_t)t * nf, scores_dev ? score : nullptr, bc, ctx, nullptr, 0, s);
+                if (rc != IDM_OK) return rc;
+            } else {
+                rc = forward_chunk(m, p, x, m->ttable + (size_t)t * nf, score, bc, cfg->precision, nullptr, 0, s);
+                if (rc != IDM_OK) return rc;
+                timed(m, "update", 0.0, (double)bc * elems * (z ? 16 : 12), s, [&] {
+                    launch_update(x, score, z, cfg->betas_host[t], bc, (int64_t)elems, cfg->add_noise != 0, ph, s);
+                });
+            }
             if (traj_dev)
                 HIPCHK(hipMemcpyAsync(traj_dev + (size_t)t * total + b0 * elems, x, bc * elems * 4, hipMemcpyDeviceToDevice, s));
         }
@@ -485,6 +647,13 @@ int idm_observe(int device, const int8_t *spins_dev, int64_t B, int L, int32_t *
     launch_observe(spins_dev, B, L, M_dev, S_dev, hist_M_dev, hist_S_dev, moments_dev, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return IDM_OK;
+}
+
+int idm_set_option(idm_model *m, const char *name, int value)
+{
+    if (!m || !name) return fail(IDM_ERR_INVALID, "null argument");
+    if (!strcmp(name, "fused")) { m->use_fused = value != 0; return IDM_OK; }
+    return fail(IDM_ERR_INVALID, std::string("unknown option ") + name);
 }
 
 int idm_profile_begin(idm_model *m)

@@ -63,3 +63,35 @@ void launch_cast_bf16_to_f32(const void *in, float *out, int64_t n, hipStream_t 
 
 // ---- bf16 kernels (idm_fast.hip) ----
 void launch_conv_bf16(const ConvArgs &a, hipStream_t s);
+
+// ---- fused two-convolution band kernels (idm_fused.hip) ----
+enum FusedKind { FK_A = 0, FK_M1 = 1, FK_M2 = 2, FK_M3 = 3, FK_B = 4 };
+
+struct FusedArgs {
+    int H, W;          // map size of this level (conv outputs)
+    int R;             // band rows (even)
+    int nbands;
+    int Hx, Wx;        // FIRST / HEAD: size of the unpadded state x
+    const void *in_a;  // PLAIN: (B,H,W,CA); UPCAT: (B,H/2,W/2,CA); FIRST: x float32 (B,Hx,Wx)
+    const void *in_b;  // UPCAT: (B,H,W,CB)
+    const void *w1;
+    const float *b1, *s1, *h1, *tadd1;
+    const void *w2;
+    const float *b2, *s2, *h2;
+    void *out;         // STORE*: (B,H,W,C2) bf16
+    void *out_pool;    // STORE_POOL: (B,H/2,W/2,C2) bf16
+    // HEAD
+    const float *w_head;
+    const float *b_head;
+    float *x;                // state, updated in place
+    float *score_out;        // optional (B,Hx,Wx)
+    const float *noise;      // optional injected standard normals (B,Hx,Wx)
+    float c1, beta, sd;
+    int add_noise, do_update;
+    PhiloxArgs ph;
+    int lds_in_bytes, lds_mid_bytes;  // region sizes (host-computed, multiples of 16)
+};
+
+
+void fused_lds_bytes(int kind, int W, int R, int *in_bytes, int *mid_bytes);
+hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s);

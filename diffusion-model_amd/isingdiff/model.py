@@ -157,6 +157,10 @@ class ScoreModel:
                                                     C.cast(arr, C.POINTER(C.c_void_p)), _stream_ptr(self.device)))
         return score, taps
 
+    def set_option(self, name: str, value: int):
+        """Tuning switch, e.g. ``set_option("fused", 0)`` forces one kernel per layer in bf16."""
+        _lib.check(_lib.load().idm_set_option(self.handle, name.encode(), int(value)))
+
     def profile_begin(self):
         """Start per-kernel event timing of this model's launches (see idm_profile_begin)."""
         with torch.cuda.device(self.device):

@@ -137,6 +137,10 @@ int idm_observe(int device, const int8_t *spins_dev, int64_t B, int L, int32_t *
                 unsigned long long *hist_M_dev, unsigned long long *hist_S_dev, long long *moments_dev,
                 void *stream);
 
+/* Tuning switches (no counterpart in the reference).  "fused" (default 1): bf16 forward uses
+ * the fused two-convolution band kernels when the shape fits; 0 forces one kernel per layer. */
+int idm_set_option(idm_model *m, const char *name, int value);
+
 /* Per-kernel timing for roofline accounting (no counterpart in the reference).  Between
  * idm_profile_begin and idm_profile_end every kernel launch of idm_forward / idm_sample on this
  * handle is bracketed by HIP events recorded on the call's own stream.  idm_profile_end

@@ -1,0 +1,141 @@
+"""CPU tests of the host logic: .keras/HDF5 loader, C-ABI surface, sharding, Onsager constants."""
+import ctypes as C
+import hashlib
+import io
+import os
+import re
+import zipfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_weight_files_are_the_reference_ones(weights_dir):
+    want = {"b_diffusion_model_2d_ising_realspace_unet.keras": "f69baf6f76a435db",
+            "b_diffusion_model_2d_ising_unet.keras": "7d2ae99bf9c78465",
+            "b_diffusion_model_2d_ising.keras": "597f85f29065ea25"}
+    for name, prefix in want.items():
+        h = hashlib.sha256(open(os.path.join(weights_dir, name), "rb").read()).hexdigest()
+        assert h.startswith(prefix), name
+
+
+def test_realspace_spec(real_spec):
+    assert real_spec.n_params == 504257 and not real_spec.batchnorm
+    assert real_spec.input_hw == (20, 20) and real_spec.channels == 1 and real_spec.base_filters == 32
+    assert real_spec.keras_version == "3.10.0"
+    k0 = real_spec.convs[0].kernel
+    assert k0.shape == (3, 3, 1, 32)
+    assert abs(k0.mean() - 1.7314e-02) < 1e-5 and abs(k0.std() - 1.1845e-01) < 1e-5
+    k6 = real_spec.convs[6].kernel
+    assert k6.shape == (3, 3, 192, 64)
+    assert abs(k6.min() + 2.6895e-01) < 1e-4 and abs(k6.max() - 1.9011e-01) < 1e-4
+    assert abs(real_spec.convs[10].bias[0] + 4.6793e-03) < 1e-6
+    assert real_spec.dense[0].kernel.shape == (1, 128)
+    assert [c.silu for c in real_spec.convs] == [True] * 10 + [False]
+    assert real_spec.pad_for(20, 20) == (0, 0) and real_spec.pad_for(18, 22) == (2, 2)
+
+
+def test_fft_unet_spec_batchnorm_is_constant_affine(fft_spec, weights_dir):
+    from isingdiff.hdf5_min import read_datasets
+    assert fft_spec.n_params == 507138 and fft_spec.batchnorm
+    assert fft_spec.input_hw == (20, 11) and fft_spec.channels == 2
+    with zipfile.ZipFile(os.path.join(weights_dir, "b_diffusion_model_2d_ising_unet.keras")) as z:
+        t = read_datasets(z.read("model.weights.h5"))
+    for i in range(10):
+        name = "batch_normalization" + (f"_{i}" if i else "")
+        assert np.all(t[f"/layers/{name}/vars/2"] == 0) and np.all(t[f"/layers/{name}/vars/3"] == 1)
+        g = t[f"/layers/{name}/vars/0"]
+        assert 0.98985 <= g.min() and g.max() <= 1.0526
+        assert np.allclose(fft_spec.convs[i].bn_scale, g / np.sqrt(np.float32(1) + np.float32(1e-3)))
+        assert np.array_equal(fft_spec.convs[i].bn_shift, t[f"/layers/{name}/vars/1"])
+    assert fft_spec.convs[10].bn_scale is None
+
+
+def test_dense_fft_file_parses(weights_dir):
+    from isingdiff.hdf5_min import read_datasets
+    with zipfile.ZipFile(os.path.join(weights_dir, "b_diffusion_model_2d_ising.keras")) as z:
+        t = read_datasets(z.read("model.weights.h5"))
+    shapes = sorted(v.shape for v in t.values() if v.ndim == 2)
+    assert (441, 440) in shapes and (440, 440) in shapes
+
+
+def test_hdf5_reader_rejects_garbage():
+    from isingdiff.hdf5_min import Hdf5FormatError, read_datasets
+    with pytest.raises(Hdf5FormatError):
+        read_datasets(b"not an hdf5 file at all")
+
+
+def test_loader_rejects_other_graphs(tmp_path, weights_dir):
+    from isingdiff.keras_file import load_unet_spec
+    src = os.path.join(weights_dir, "b_diffusion_model_2d_ising.keras")   # dense MLP, not the UNet
+    with pytest.raises((ValueError, KeyError)):
+        load_unet_spec(src)
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "isingdiff.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(idm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads without a GPU and exports exactly what include/isingdiff.h declares."""
+    from isingdiff import _lib
+    declared = _declared_symbols()
+    assert declared, "no declarations parsed"
+    assert sorted(_lib.SIGNATURES) == declared
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.idm_abi_version.restype = C.c_int
+    assert lib.idm_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    from isingdiff import _lib
+    assert C.sizeof(_lib.ModelDesc) == 16 + 8 * (4 * 11 + 2 * 3)
+    assert C.sizeof(_lib.SampleCfg) == 48
+    assert C.sizeof(_lib.ProfileEntry) == 32 + 8 * 4
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "diffusion-model_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(d, f)).read()
+                assert "oracle" not in src.replace("oracle's", ""), f"{f} mentions the oracle"
+
+
+def test_shard_range_partitions():
+    from isingdiff.distributed import shard_range
+    for n, w in ((65536, 8), (10, 3), (7, 8), (0, 4)):
+        blocks = [shard_range(n, r, w) for r in range(w)]
+        assert blocks[0][0] == 0 and sum(c for _, c in blocks) == n
+        for (f0, c0), (f1, _) in zip(blocks, blocks[1:]):
+            assert f0 + c0 == f1
+    with pytest.raises(ValueError):
+        shard_range(4, 4, 4)
+
+
+def test_onsager_known_answers():
+    """Values obtained from the reference's onsager.py (scipy ellipk/ellipe)."""
+    from isingdiff import onsager_energy, onsager_heat_capacity, onsager_magnetization
+    for kT, e in ((2.0, -1.7455645753), (2.5, -1.1060792037), (2.2691, -1.4146594891), (1.5, -1.9511165731),
+                  (3.0, -0.8173095925)):
+        assert abs(onsager_energy(kT, 1.0) - e) < 1e-9
+    assert abs(onsager_magnetization(2.0, 1.0) - 0.9113193779) < 1e-9
+    assert onsager_magnetization(2.5, 1.0) == 0.0
+    assert abs(onsager_heat_capacity(2.0, 1.0) - 2.8994857944) < 1e-8
+
+
+def test_gpu_only_entry_points_fail_loudly_without_a_gpu(real_spec):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from isingdiff import _lib
+    from isingdiff.model import ScoreModel
+    with pytest.raises(_lib.IdmError):
+        ScoreModel(real_spec)

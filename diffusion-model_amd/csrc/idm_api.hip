@@ -156,7 +156,7 @@ int pick_band_rows(int kind, int H, int W)
         if ((R & 1) && kind != FK_M2) continue;
         int in = 0, mid = 0;
         fused_lds_bytes(kind, W, R, &in, &mid);
-        if (in + mid <= limit) return R;
+        if (in + mid <= limit && fused_band_fits(kind, W, R)) return R;
     }
     return 0;
 }
@@ -269,7 +269,7 @@ int forward_fused(idm_model *m, const Plan &p, const float *x, const float *tadd
     const double n1 = (double)Bc * Hp * Wp, n2 = n1 / 4, n4 = n1 / 16;
     auto run = [&](int kind, const char *name, FusedArgs &a, int H, int W, double flop, double bytes) -> int {
         a.H = H; a.W = W; a.R = p.R[kind]; a.nbands = (H + a.R - 1) / a.R;
-        a.Hx = p.H; a.Wx = p.W;
+        a.Hx = p.H; a.Wx = p.W; a.B = Bc;
         fused_lds_bytes(kind, W, a.R, &a.lds_in_bytes, &a.lds_mid_bytes);
         hipError_t e = hipSuccess;
         timed(m, name, flop, bytes, s, [&] { e = launch_fused(kind, a, Bc, s); });

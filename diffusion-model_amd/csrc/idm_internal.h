@@ -90,8 +90,10 @@ struct FusedArgs {
     int add_noise, do_update;
     PhiloxArgs ph;
     int lds_in_bytes, lds_mid_bytes;  // region sizes (host-computed, multiples of 16)
+    int64_t B;                        // lattices in this launch (bands = B * nbands, walked persistently)
 };
 
 
 void fused_lds_bytes(int kind, int W, int R, int *in_bytes, int *mid_bytes);
+bool fused_band_fits(int kind, int W, int R);
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s);

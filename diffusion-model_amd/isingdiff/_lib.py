@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libisingdiff.so")
+LIB_PATH = os.environ.get("ISINGDIFF_LIB") or os.path.join(_HERE, "libisingdiff.so")
 
 IDM_FP32 = 0
 IDM_BF16 = 1

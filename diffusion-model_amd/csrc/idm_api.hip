@@ -649,6 +649,17 @@ int idm_observe(int device, const int8_t *spins_dev, int64_t B, int L, int32_t *
     return IDM_OK;
 }
 
+int idm_irfft2_sign(int device, const float *spec_dev, int64_t B, int L, int8_t *spins_dev, double *real_dev, void *stream)
+{
+    if (!spec_dev || !spins_dev || B <= 0) return fail(IDM_ERR_INVALID, "bad argument");
+    if (L < 2 || (L & 1)) return fail(IDM_ERR_UNSUPPORTED, "irfft2 needs an even lattice size");
+    if ((size_t)(2 * L + 4 * L * (L / 2 + 1)) * sizeof(double) > 160 * 1024)
+        return fail(IDM_ERR_UNSUPPORTED, "lattice too large for the LDS-resident transform (L <= 98 in float64)");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(launch_irfft2_sign(spec_dev, B, L, spins_dev, real_dev, (hipStream_t)stream));
+    return IDM_OK;
+}
+
 int idm_set_option(idm_model *m, const char *name, int value)
 {
     if (!m || !name) return fail(IDM_ERR_INVALID, "null argument");

@@ -407,3 +407,74 @@ void launch_cast_bf16_to_f32(const void *in, float *out, int64_t n, hipStream_t 
 {
     hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const __bf16 *)in, out, n);
 }
+
+// ---------------------------------------------------------------------------------------------
+// irfft2 + sign projection for the spectral model (b_fft.py:12-17 then
+// b_diffusion_model_fft_unet_2d_ising.py:214-217).  One workgroup per lattice, everything in LDS,
+// float64 arithmetic.  Same order as numpy.fft.irfft2: a complex inverse transform along axis 0
+// for each of the L/2+1 stored columns, then a complex-to-real transform along axis 1 that uses
+// only the real parts of the k=0 and k=L/2 columns, normalised by 1/L^2.  The transforms are
+// direct sums over a cos/sin table (L <= 128: O(L^3) per lattice, once per sample, negligible
+// next to the 1000 UNet evaluations).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void irfft2_sign_kernel(const float *__restrict__ spec, int L, int8_t *__restrict__ spins,
+                                                          double *__restrict__ real_out)
+{
+    extern __shared__ __attribute__((aligned(16))) char irf_smem[];
+    const int K = L / 2 + 1;
+    double *cs = (double *)irf_smem;          // cos(2 pi q / L), q < L
+    double *sn = cs + L;                      // sin(2 pi q / L)
+    double *xr = sn + L;                      // input  [m][k]
+    double *xi = xr + L * K;
+    double *yr = xi + L * K;                  // after axis 0 [n][k]
+    double *yi = yr + L * K;
+    const int64_t b = blockIdx.x;
+    const float *src = spec + b * (int64_t)L * K * 2;
+    for (int q = threadIdx.x; q < L; q += 256) {
+        double s, c;
+        sincospi(2.0 * q / L, &s, &c);
+        cs[q] = c; sn[q] = s;
+    }
+    for (int i = threadIdx.x; i < L * K; i += 256) { xr[i] = src[2 * i]; xi[i] = src[2 * i + 1]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * K; i += 256) {
+        const int n = i / K, k = i - n * K;
+        double ar = 0.0, ai = 0.0;
+        int q = 0;
+        for (int m = 0; m < L; ++m) {
+            const double c = cs[q], s = sn[q], vr = xr[m * K + k], vi = xi[m * K + k];
+            ar += vr * c - vi * s;
+            ai += vr * s + vi * c;
+            q += n; if (q >= L) q -= L;
+        }
+        yr[i] = ar; yi[i] = ai;
+    }
+    __syncthreads();
+    const double norm = 1.0 / ((double)L * L);
+    for (int i = threadIdx.x; i < L * L; i += 256) {
+        const int n = i / L, j = i - n * L;
+        double acc = yr[n * K] + ((j & 1) ? -yr[n * K + L / 2] : yr[n * K + L / 2]);
+        int q = j;
+        for (int k = 1; k < L / 2; ++k) {
+            acc += 2.0 * (yr[n * K + k] * cs[q] - yi[n * K + k] * sn[q]);
+            q += j; if (q >= L) q -= L;
+        }
+        acc *= norm;
+        if (real_out) real_out[b * (int64_t)L * L + i] = acc;
+        spins[b * (int64_t)L * L + i] = acc > 0.0 ? 1 : -1;
+    }
+}
+
+hipError_t launch_irfft2_sign(const float *spec, int64_t B, int L, int8_t *spins, double *real_out, hipStream_t s)
+{
+    const int K = L / 2 + 1;
+    const size_t lds = (size_t)(2 * L + 4 * L * K) * sizeof(double);
+    static thread_local bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)irfft2_sign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(irfft2_sign_kernel, dim3((unsigned)B), dim3(256), lds, s, spec, L, spins, real_out);
+    return hipGetLastError();
+}

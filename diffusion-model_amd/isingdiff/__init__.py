@@ -14,13 +14,14 @@ from .onsager import onsager_energy, onsager_heat_capacity, onsager_magnetizatio
 __all__ = ["UNetSpec", "load_unet_spec", "onsager_energy", "onsager_heat_capacity", "onsager_magnetization",
            "theoretical_critical_kT", "load_model", "ScoreModel", "diffusion_backward", "sample", "beta_schedule",
            "observe", "sign_project", "ising_energy", "ising_magnetization", "Observables", "shard_range",
-           "allreduce_observables"]
+           "allreduce_observables", "irfft2_sign"]
 
 _LAZY = {
     "load_model": "model", "ScoreModel": "model",
     "diffusion_backward": "sampler", "sample": "sampler", "beta_schedule": "sampler", "SampleResult": "sampler",
     "observe": "observables", "sign_project": "observables", "ising_energy": "observables",
     "ising_magnetization": "observables", "Observables": "observables",
+    "irfft2_sign": "spectral",
     "shard_range": "distributed", "allreduce_observables": "distributed",
 }
 

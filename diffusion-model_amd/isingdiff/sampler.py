@@ -90,13 +90,16 @@ class SampleResult:
 
 def sample(model: ScoreModel, n: int, L: int, *, T: int = 1000, betas=None, seed: int = 42, precision=None,
            first_global_index: int = 0, chunk: int = 0, keep_state: bool = False, observables: bool = True,
-           x_T=None, noise=None) -> SampleResult:
+           x_T=None, noise=None, width: Optional[int] = None) -> SampleResult:
     """Draw ``n`` L×L lattices: x_T ~ N(0,1) (Philox, keyed by the global lattice index), the full
     reverse schedule, sign projection (:203-213) and — for single-channel models — the Ising
     observables.  Everything stays on the GPU."""
     prec = model.precision if precision is None else _precision_code(precision)
     betas = beta_schedule(T) if betas is None else np.asarray(betas, np.float32)
-    shape = (n, L, L, model.channels)
+    # spectral models (C = 2) diffuse the rfft2 spectrum: state (n, L, L//2+1, 2)
+    if width is None:
+        width = L // 2 + 1 if model.channels == 2 else L
+    shape = (n, L, width, model.channels)
     if x_T is None:
         x = torch.empty(shape, dtype=torch.float32, device=model.device)
         init = True
@@ -109,8 +112,11 @@ def sample(model: ScoreModel, n: int, L: int, *, T: int = 1000, betas=None, seed
         _run(model, x, betas, T, noise=z, traj=None, scores=None, spins=spins, precision=prec, seed=seed,
              first_global_index=first_global_index, init_state=init, add_noise=True, chunk=chunk)
     obs = None
-    if model.channels == 1:
+    if model.channels == 2 and width == L // 2 + 1 and n > 0:
+        from .spectral import irfft2_sign
+        spins = irfft2_sign(x)          # b_diffusion_model_fft_unet_2d_ising.py:214-217
+    elif model.channels == 1 and width == L:
         spins = spins.reshape(n, L, L)
-        if observables and n > 0:
-            obs = observe(spins)
+    if observables and n > 0 and spins.dim() == 3:
+        obs = observe(spins)
     return SampleResult(spins, obs, x if keep_state else None)

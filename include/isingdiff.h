@@ -137,6 +137,14 @@ int idm_observe(int device, const int8_t *spins_dev, int64_t B, int L, int32_t *
                 unsigned long long *hist_M_dev, unsigned long long *hist_S_dev, long long *moments_dev,
                 void *stream);
 
+/* Spectral model post-processing: ising_ifft = np.fft.irfft2(re + 1j*im, s=(L,L)) (b_fft.py:12-17)
+ * followed by np.where(x > 0, 1, -1) (b_diffusion_model_fft_unet_2d_ising.py:214-217).
+ * spec_dev (B, L, L/2+1, 2) float32 (Re, Im); spins_dev (B,L,L) int8; real_dev NULL or (B,L,L) float64
+ * receiving the transform itself.  numpy's axis order (complex transform along axis 0, then
+ * complex-to-real along axis 1), float64 arithmetic, even L. */
+int idm_irfft2_sign(int device, const float *spec_dev, int64_t B, int L, int8_t *spins_dev, double *real_dev,
+                    void *stream);
+
 /* Tuning switches (no counterpart in the reference).  "fused" (default 1): bf16 forward uses
  * the fused two-convolution band kernels when the shape fits; 0 forces one kernel per layer. */
 int idm_set_option(idm_model *m, const char *name, int value);

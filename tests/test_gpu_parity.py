@@ -97,6 +97,23 @@ def test_bf16_fused_matches_per_layer_kernels(gpu_real, B, H, W, t):
     assert e < BF16_SCORE_TOL, e
 
 
+@pytest.mark.parametrize("L", [64, 128])
+def test_large_lattices(gpu_real, real_spec, ref_real, L):
+    """The L=20-trained weights applied convolutionally at L=64 / 128 (BASELINE config 3):
+    fp32 bit-exact, bf16 within tolerance."""
+    from oracle import ref_cpu
+    rng = np.random.default_rng(L)
+    x = ising_like(rng, 1, L, L, 700)
+    tn = np.float32(0.7)
+    want = ref_real.forward(x, tn)
+    got = gpu_real([x, tn], precision="fp32")
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    want_q = ref_cpu.RefModel(real_spec, quant_bf16=True).forward(x, tn)
+    got16 = gpu_real([x, tn], precision="bf16")
+    assert rel_l2(got16, want_q) < BF16_LAYER_TOL
+    assert rel_l2(got16, want) < BF16_SCORE_TOL
+
+
 def test_call_and_predict_interfaces(gpu_real, ref_real):
     import torch
     rng = np.random.default_rng(3)

@@ -183,7 +183,8 @@ Plan make_plan(const idm_model *m, int H, int W, int precision)
     p.off_a9 = take(n1 * F * 4);
     p.off_score = take((size_t)H * W * m->C * 4);
     p.per_lattice = o;
-    p.fused = precision == IDM_BF16 && m->C == 1 && m->use_fused && m->w_first_pack != nullptr;
+    // the fused band kernels cover the real-space model (one state channel, no BatchNorm)
+    p.fused = precision == IDM_BF16 && m->C == 1 && !m->bn && m->use_fused && m->w_first_pack != nullptr;
     if (p.fused) {
         const int hh[5] = {p.Hp, p.Hp / 2, p.Hp / 4, p.Hp / 2, p.Hp}, ww[5] = {p.Wp, p.Wp / 2, p.Wp / 4, p.Wp / 2, p.Wp};
         for (int k = 0; k < 5; ++k) {
@@ -278,8 +279,8 @@ int forward_fused(idm_model *m, const Plan &p, const float *x, const float *tadd
     };
     auto layer = [&](FusedArgs &a, int l1, int l2) {
         a.w1 = l1 == 0 ? m->w_first_pack : m->wpack_bf16[l1];
-        a.b1 = m->bias[l1]; a.s1 = m->scale[l1]; a.h1 = m->shift[l1];
-        a.w2 = m->wpack_bf16[l2]; a.b2 = m->bias[l2]; a.s2 = m->scale[l2]; a.h2 = m->shift[l2];
+        a.b1 = m->bias[l1];
+        a.w2 = m->wpack_bf16[l2]; a.b2 = m->bias[l2];
     };
     int rc;
     {   // x -> conv0 -> conv1 -> skip1 (+ pooled)

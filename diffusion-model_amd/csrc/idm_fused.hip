@@ -32,11 +32,25 @@ constexpr int WG = 256;
 enum { M1_PLAIN = 0, M1_UPCAT = 1, M1_FIRST = 2 };
 enum { E2_STORE = 0, E2_STORE_POOL = 1, E2_HEAD = 2 };
 
-#ifdef IDM_ABL_NOEPI
-DEVI float fsilu(float y) { return y; }
-#else
-DEVI float fsilu(float y) { return y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)); }
-#endif
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// silu of four values, written on float pairs so that everything but the two transcendentals
+// (v_exp_f32, v_rcp_f32: quarter rate) goes through the packed float32 ALU.
+DEVI f32x4 silu4(f32x4 z)
+{
+    const f32x2 nl = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.0f, 1.0f};
+    f32x2 z0 = {z[0], z[1]}, z1 = {z[2], z[3]};
+    f32x2 t0 = z0 * nl, t1 = z1 * nl;
+    f32x2 e0 = {__builtin_amdgcn_exp2f(t0[0]), __builtin_amdgcn_exp2f(t0[1])};
+    f32x2 e1 = {__builtin_amdgcn_exp2f(t1[0]), __builtin_amdgcn_exp2f(t1[1])};
+    e0 = e0 + one;
+    e1 = e1 + one;
+    f32x2 r0 = {__builtin_amdgcn_rcpf(e0[0]), __builtin_amdgcn_rcpf(e0[1])};
+    f32x2 r1 = {__builtin_amdgcn_rcpf(e1[0]), __builtin_amdgcn_rcpf(e1[1])};
+    z0 = z0 * r0;
+    z1 = z1 * r1;
+    return f32x4{z0[0], z0[1], z1[0], z1[1]};
+}
 
 DEVI bf16x4 pack4(float a, float b, float c, float d)
 {
@@ -53,142 +67,247 @@ DEVI void static_for(F &&f)
     }
 }
 
-// One convolution stage over `npix` output pixels (pixel p -> row r0 + p / W, column p % W of the
-// stage's output region).  NT pixel tiles and MS cout tiles are accumulated together per wave.
-//   PLAIN part: operand for tap (ky,kx), channel group cg at  tile + ((r+ky)*(W+2) + x+kx)*S + 32*cg
-//   UP part:    the same on the half-resolution tile at row (r+ky)>>1, column (x+kx+1)>>1
-// The 9*NCG K-steps are fully unrolled so that every register index is static.  Activation
-// fragments run PD steps ahead of the MFMAs in a small register ring (LDS latency), weights one
-// whole tap ahead in a second register set (L2 latency); per-lane LDS addresses are sums of
-// values computed once per tile, so the loop body holds no integer multiplies.
-template <int CA, int CB, bool UP, int COUT, int NT, int MS, class Epi>
-DEVI void conv_stage(const char *lds_a, const char *lds_b, int W, int r0, int npix, const bf16x8 *__restrict__ wp,
-                     int wave, int lane, Epi &&epi)
+// Buffer addressing: one scalar resource per tensor, a 32-bit per-lane byte offset and a scalar
+// constant per access (no 64-bit per-lane address arithmetic); reads beyond `bytes` return zero.
+DEVI __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
 {
-    constexpr int MTOT = COUT / 32, NSL = MTOT / MS;
-    constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16;
-    constexpr int NCG_A = CA / 16, NCG_B = CB / 16, NCG = NCG_A + NCG_B;
-    constexpr int NSTEP = 9 * NCG;
-    constexpr int PD = 2;
-    constexpr int WC = 6 / MS;  // K-steps per weight chunk (divides 9*NCG for every layer shape)
-    static_assert(NSTEP % WC == 0, "weight chunk must divide the K loop");
-    const int ntiles = (npix + 31) >> 5, ngroups = (ntiles + NT - 1) / NT;
-    const int h = lane >> 5, li = lane & 31;
-    const int Wp2 = W + 2, Wh2 = (W >> 1) + 2;
-    wp += lane;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
 
-#pragma unroll 1
-    for (int u = wave; u < ngroups * NSL; u += 4) {
-        const int grp = u / NSL, sl = u - grp * NSL;
-        int pr[NT], px[NT];
-        bool valid[NT];
-        int base_a[NT], base_b[NT], row_a[3][NT], col_a[3][NT];
+DEVI bf16x8 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// Per-lane geometry of the 32-pixel MFMA tiles of a map of width W, fixed for a kernel launch.
+// W <= 32: a tile is TR = 32 / W row slots of W pixels; lane li sits in slot li / W, column li % W,
+// and slot s of tile j is row j + s * Rh of the stage's output region (Rh = ceil(rows / TR)), so
+// that vertically adjacent tiles j, j+1, ... touch input rows that differ by exactly one.
+// W > 32: a tile is 32 consecutive columns of one row (ncb column blocks).
+struct LaneGeo {
+    int W, ncb, TR, slot, col;
+    bool ok;
+};
+
+DEVI LaneGeo make_geo(int W, int li)
+{
+    LaneGeo g;
+    g.W = W;
+    g.ncb = (W + 31) >> 5;
+    if (g.ncb == 1) {
+        g.TR = 32 / W;
+        g.slot = li / W;
+        g.col = li - g.slot * W;
+        g.ok = g.slot < g.TR;
+        if (!g.ok) g.slot = 0;
+    } else {
+        g.TR = 1;
+        g.slot = 0;
+        g.col = li;
+        g.ok = true;
+    }
+    return g;
+}
+
+// One 3x3 convolution stage over `nrows` output rows of an LDS-resident input tile.
+//
+// Work is cut into (cout slice, column block, row j) items and split evenly over the four
+// wavefronts; a wavefront processes up to NT vertically adjacent tiles at once.  Because tile n's
+// operand for tap row ky is input row j + n + ky, the NT + 2 activation fragments of one
+// (kx, channel group) "superstep" feed all 3 * NT MFMAs of that superstep: LDS traffic drops from
+// one 1 KB read per MFMA to (NT + 2) / (3 * NT * MS).  Supersteps are fully unrolled (static
+// register indices); activation fragments are read one superstep ahead, weights WD supersteps
+// ahead (L2 latency) into a register ring.  begin() fixes the partition and issues the first WD
+// weight fetches, so the caller can place it ahead of a barrier or a long-latency phase; run()
+// does the rest.
+//   PLAIN part: operand at  tile + ((row + ky)*(W+2) + col + kx)*S + 32*cg
+//   UP part:    the same on the half-resolution tile at row (row+ky)>>1, column (col+kx+1)>>1
+// Epilogue constants: c0 (bias) and, when HAS_C1, a second per-cout array c1 live in LDS as float32;
+// the 16 values a lane needs per cout tile are read during the last superstep and handed to epi().
+template <int CA, int CB, bool UP, int COUT, int NT, int MS, int WD, bool HAS_C1>
+struct ConvStage {
+    static constexpr int MTOT = COUT / 32, NSL = MTOT / MS;
+    static constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16;
+    static constexpr int NCG_A = CA / 16, NCG_B = CB / 16, NCG = NCG_A + NCG_B;
+    static constexpr int NS = 3 * NCG;
+    static constexpr int NPRE = WD < NS ? WD : NS;       // supersteps of weights fetched by begin()
+    static constexpr int WR = WD < NS ? WD + 1 : NS;     // ring slots
+    static constexpr bool FULL = WD >= NS;               // every weight of the stage is fetched by begin()
+
+    const char *lds_a, *lds_b;
+    const float *c0, *c1;
+    __amdgpu_buffer_rsrc_t wrsrc;   // weights: every fetch is buffer(base) + scalar constant + one 32-bit lane offset
+    unsigned wlane, woff;
+    LaneGeo g;
+    int h, r0, nrows, Rh, f, f1;
+    bf16x8 wreg[WR][3][MS];
+
+    DEVI void set_slice(int sl)
+    {
+        // The slice offset is made opaque to the optimiser: otherwise the weight loads are
+        // invariant across work items and get hoisted into (far too many) registers.  Laundering
+        // the offset, not the pointer, keeps the loads global_load: a laundered pointer degrades
+        // to flat_load, which also counts on lgkmcnt and turns every LDS wait into a wait for
+        // the weight prefetch.
+        unsigned o = (wlane + (unsigned)(sl * MS * 64)) * 16u;  // byte offset
+        asm volatile("" : "+v"(o));
+        woff = o;
+    }
+
+    template <int S>
+    DEVI void issue_w()
+    {
+        constexpr int kx = S / NCG, cg = S % NCG;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int p = (grp * NT + n) * 32 + li;
-            valid[n] = p < npix;
-            const int pc = valid[n] ? p : 0;
-            const int q = pc / W;
-            pr[n] = q + r0;
-            px[n] = pc - q * W;
-            if constexpr (UP) {
-                const int rs = Wh2 * SA;
-                row_a[0][n] = (pr[n] >> 1) * rs;
-                row_a[1][n] = row_a[0][n] + (pr[n] & 1) * rs;
-                row_a[2][n] = row_a[0][n] + rs;
-                col_a[0][n] = ((px[n] + 1) >> 1) * SA + h * 16;
-                col_a[1][n] = ((px[n] >> 1) + 1) * SA + h * 16;
-                col_a[2][n] = col_a[0][n] + SA;
-            } else {
-                base_a[n] = (pr[n] * Wp2 + px[n]) * SA + h * 16;
-            }
-            base_b[n] = (pr[n] * Wp2 + px[n]) * SB + h * 16;
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int m = 0; m < MS; ++m) wreg[S % WR][ky][m] = buf_load16(wrsrc, woff, (((ky * 3 + kx) * NCG + cg) * MTOT + m) * 1024);
+    }
+
+    DEVI void prologue()
+    {
+        static_for<0, NPRE>([&](auto S) { issue_w<decltype(S)::value>(); });
+    }
+
+    DEVI void begin(const char *la, const char *lb, const float *c0_, const float *c1_, const LaneGeo &geo, int r0_,
+                    int nrows_, const bf16x8 *w, int wave, int lane)
+    {
+        lds_a = la; lds_b = lb; c0 = c0_; c1 = c1_; g = geo; h = lane >> 5; r0 = r0_; nrows = nrows_;
+        wrsrc = make_rsrc(w, 9u * (CA + CB) * COUT * 2u);
+        wlane = (unsigned)lane;
+        Rh = (nrows + g.TR - 1) / g.TR;
+        const int tot = NSL * g.ncb * Rh;
+        f = (wave * tot) >> 2;
+        f1 = ((wave + 1) * tot) >> 2;
+        if (f < f1) {
+            set_slice((f / Rh) % NSL);
+            prologue();
         }
-        (void)base_a; (void)base_b; (void)row_a; (void)col_a;
-        f32x16 acc[MS][NT];
+    }
+
+    template <int N, class Epi>
+    DEVI void piece(int j, int sl, int cb, Epi &&epi)
+    {
+        const int W = g.W, Wp2 = W + 2, Wh2 = (W >> 1) + 2;
+        const int cc = cb * 32 + g.col;
+        const int ca = min(cc, W - 1);
+        const int rbase = r0 + j + g.slot * Rh, rmax = r0 + nrows + 1;
+        int a_pl[N + 2], a_up[N + 2], a_b[N + 2], c_up[3];
+#pragma unroll
+        for (int i = 0; i < N + 2; ++i) {
+            const int r = min(rbase + i, rmax);
+            if constexpr (UP) a_up[i] = (r >> 1) * (Wh2 * SA);
+            else a_pl[i] = (r * Wp2 + ca) * SA + h * 16;
+            a_b[i] = (r * Wp2 + ca) * SB + h * 16;
+        }
+        if constexpr (UP) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) c_up[kx] = ((ca + kx + 1) >> 1) * SA + h * 16;
+        }
+        (void)a_pl; (void)a_up; (void)a_b; (void)c_up;
+
+        f32x16 acc[MS][N];
 #pragma unroll
         for (int m = 0; m < MS; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
+            for (int n = 0; n < N; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
-        // The slice offset is made opaque to the optimiser: otherwise the weight loads are
-        // loop-invariant across tile groups and get hoisted out of this loop into (far too many)
-        // registers.  (Laundering the offset, not the pointer, keeps the loads global_load: a
-        // laundered pointer degrades to flat_load, which also counts on lgkmcnt and turns every
-        // LDS wait into a wait for the weight prefetch.)
-        int woff = sl * MS * 64;
-        asm volatile("" : "+v"(woff));
-        const bf16x8 *wsl = wp + woff;
-        bf16x8 wreg[2][WC][MS];
-        bf16x8 ring[PD + 1][NT];
-        auto load_w = [&](auto CHUNK) {
-            constexpr int ch = decltype(CHUNK)::value;
-            const bf16x8 *wt = wsl + (size_t)(ch * WC) * MTOT * 64;
-#pragma unroll
-            for (int k = 0; k < WC; ++k)
-#pragma unroll
-                for (int m = 0; m < MS; ++m) wreg[ch & 1][k][m] = wt[(k * MTOT + m) * 64];
-        };
-        auto read_b = [&](auto S) {
+        bf16x8 fr[2][N + 2];
+        auto read_f = [&](auto S) {
             constexpr int st = decltype(S)::value;
-            constexpr int tap = st / NCG, cg = st % NCG, ky = tap / 3, kx = tap % 3, slot = st % (PD + 1);
-            if constexpr (cg < NCG_A) {
+            constexpr int kx = st / NCG, cg = st % NCG;
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
+            for (int i = 0; i < N + 2; ++i) {
+                if constexpr (cg < NCG_A) {
                     int addr;
-                    if constexpr (UP) addr = row_a[ky][n] + col_a[kx][n];
-                    else addr = base_a[n] + (ky * Wp2 + kx) * SA;
-                    ring[slot][n] = *(const bf16x8 *)(lds_a + addr + cg * 32);
+                    if constexpr (UP) addr = a_up[i] + c_up[kx];
+                    else addr = a_pl[i] + kx * SA;
+                    fr[st & 1][i] = *(const bf16x8 *)(lds_a + addr + cg * 32);
+                } else {
+                    fr[st & 1][i] = *(const bf16x8 *)(lds_b + a_b[i] + kx * SB + (cg - NCG_A) * 32);
                 }
-            } else {
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    ring[slot][n] = *(const bf16x8 *)(lds_b + base_b[n] + (ky * Wp2 + kx) * SB + (cg - NCG_A) * 32);
             }
         };
-        load_w(std::integral_constant<int, 0>{});
-        static_for<0, PD>([&](auto S) { read_b(S); });
-        static_for<0, NSTEP>([&](auto S) {
-            constexpr int st = decltype(S)::value;
-            constexpr int ch = st / WC, k = st % WC;
-            // pin the software pipeline: without this the scheduler hoists every load of the
-            // unrolled K loop to the top and spills
-            __builtin_amdgcn_sched_barrier(0);
-#ifdef IDM_ABL_NOW
-            if constexpr (k == 0 && ch == 0) load_w(std::integral_constant<int, 1>{});
-#else
-            if constexpr (k == 0 && (ch + 1) * WC < NSTEP) load_w(std::integral_constant<int, ch + 1>{});
-#endif
-#ifdef IDM_ABL_NOB
-            if constexpr (st == 0) read_b(std::integral_constant<int, PD>{});
-#else
-            if constexpr (st + PD < NSTEP) read_b(std::integral_constant<int, st + PD>{});
-#endif
+        f32x4 k0[MS][4], k1[MS][4];
+        if constexpr (!HAS_C1) {
 #pragma unroll
             for (int m = 0; m < MS; ++m)
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
-#ifdef IDM_ABL_NOMFMA
-                    acc[m][n][0] += (float)wreg[ch & 1][k][m][0] + (float)ring[st % (PD + 1)][n][0];
-#else
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[ch & 1][k][m], ring[st % (PD + 1)][n], acc[m][n], 0, 0, 0);
-#endif
+                for (int q = 0; q < 4; ++q) k1[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        read_f(std::integral_constant<int, 0>{});
+        static_for<0, NS>([&](auto S) {
+            constexpr int st = decltype(S)::value;
+            // pin the software pipeline: without this the scheduler hoists every load of the
+            // unrolled loop to the top and spills
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (st + NPRE < NS) issue_w<st + NPRE>();
+            if constexpr (st + 1 < NS) read_f(std::integral_constant<int, st + 1>{});
+            if constexpr (st == NS - 1) {
+#pragma unroll
+                for (int m = 0; m < MS; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int co = (sl * MS + m) * 32 + 8 * q + 4 * h;
+                        k0[m][q] = *(const f32x4 *)(c0 + co);
+                        if constexpr (HAS_C1) k1[m][q] = *(const f32x4 *)(c1 + co);
+                    }
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int m = 0; m < MS; ++m)
+#pragma unroll
+                    for (int n = 0; n < N; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[st % WR][ky][m], fr[st & 1][n + ky],
+                                                                            acc[m][n], 0, 0, 0);
         });
 #pragma unroll
         for (int m = 0; m < MS; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) epi(acc[m][n], sl * MS + m, pr[n], px[n], valid[n]);
+            for (int n = 0; n < N; ++n)
+                epi(acc[m][n], k0[m], k1[m], sl * MS + m, rbase + n, cc, g.ok && cc < W && j + n + g.slot * Rh < nrows);
     }
-}
+
+    template <class Epi>
+    DEVI void run(Epi &&epi)
+    {
+        bool fetched = true;
+#pragma unroll 1
+        while (f < f1) {
+            const int u = f / Rh, j = f - u * Rh;
+            const int len = min(f1 - f, Rh - j);
+            const int np = (len + NT - 1) / NT, cnt = (len + np - 1) / np;
+            const int sl = u % NSL, cb = u / NSL;
+            if (!fetched) {
+                set_slice(sl);
+                prologue();
+            }
+            fetched = false;
+            static_for<1, NT + 1>([&](auto N) {
+                if (cnt == decltype(N)::value) piece<decltype(N)::value>(j, sl, cb, epi);
+            });
+            f += cnt;
+        }
+    }
+};
 
 // First layer (Cin = 1): K = 9 taps in one MFMA step; x = hi + lo in bf16, two MFMAs per tile.
 // xs: float32 tile [(rows)][W+2].  wfirst: one A fragment (lane l: cout l&31, k = 8*(l>>5)+j -> tap k).
 template <class Epi>
-DEVI void conv_first_stage(const float *xs, int W, int r0, int npix, const bf16x8 *__restrict__ wfirst, int wave,
-                           int lane, Epi &&epi)
+DEVI void conv_first_stage(const float *xs, const float *c0, int W, int r0, int npix, const bf16x8 *__restrict__ wfirst,
+                           int wave, int lane, Epi &&epi)
 {
+    f32x4 k0[4], k1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        k0[q] = *(const f32x4 *)(c0 + 8 * q + 4 * (lane >> 5));
+        k1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const int ntiles = (npix + 31) >> 5;
     const int h = lane >> 5, li = lane & 31, Wp2 = W + 2;
     const bf16x8 a = wfirst[lane];
@@ -219,7 +338,7 @@ DEVI void conv_first_stage(const float *xs, int W, int r0, int npix, const bf16x
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hi, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, lo, acc, 0, 0, 0);
-        epi(acc, 0, r, x, valid);
+        epi(acc, k0, k1, 0, r, x, valid);
     }
 }
 
@@ -233,21 +352,18 @@ struct TileRegs {
     static constexpr int S = C * 2 + 16, CH = C / 8;
     bf16x8 v[NP];
 
+    // src: this lattice's map (Hmap rows); rows outside it, and items beyond the tile, read as zero
+    // through the buffer range check (their offsets wrap to >= 2^31).
     DEVI void load(const __bf16 *__restrict__ src, int Hmap, int W, int g0, int nrows, int tid)
     {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, (unsigned)(Hmap * W * C * 2));
         const int ipr = W * CH;
         int row = tid / ipr, rem = tid - row * ipr;
         const int drow = WG / ipr, drem = WG - drow * ipr;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            bf16x8 z;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f;
-            const int g = g0 + row;
-#ifndef IDM_ABL_NOSTAGE
-            if (row < nrows && g >= 0 && g < Hmap) z = *(const bf16x8 *)(src + ((size_t)g * W + rem / CH) * C + (rem % CH) * 8);
-#endif
-            v[k] = z;
+            const int off = ((g0 + row) * ipr + rem) * 16;
+            v[k] = buf_load16(rs, row < nrows ? (unsigned)off : 0x80000000u, 0);
             rem += drem;
             row += drow;
             if (rem >= ipr) { rem -= ipr; ++row; }
@@ -295,8 +411,31 @@ DEVI void clear_halo(char *tile, int W, int nrows, int z0, int z1, int tid)
 
 }  // namespace
 
+#ifdef IDM_TIMELINE
+// Debug build only: phase timestamps of one workgroup (wavefronts 0 and 3), [kind][wave sel][band][stamp].
+__device__ long long g_tl[5][2][64][10];
+extern "C" int idm_debug_timeline(long long *host)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl), sizeof(g_tl));
+}
+#define TL(i)                                                                                          \
+    do {                                                                                               \
+        if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 3) && tl_it < 64)                    \
+            g_tl[TLK][wave == 3][tl_it][i] = (i) == 9 ? (long long)wall_clock64() : (long long)clock64(); \
+    } while (0)
+#else
+#define TL(i) do { } while (0)
+#endif
+
 // Persistent: each workgroup walks bands wg = blockIdx.x, blockIdx.x + gridDim.x, ...
-template <int MODE1, int CA, int CB, int C1, int C2, int EPI2, int NT1, int MS1, int NT2, int MS2, int NPA, int NPB>
+//
+// Vector-memory results return in issue order, so a wait for a weight fragment also waits for
+// every older load or store of the wavefront.  The loop is therefore arranged so that long-latency
+// traffic is always YOUNGER than the weights the next convolution needs first:
+//     conv2 -> [weights of the next band's conv1] -> [next band's input into registers] -> copy-out
+// and, where conv2's weights fit in registers as a whole (WD2 >= its supersteps), the next band's
+// input is requested even before conv2.
+template <int MODE1, int CA, int CB, int C1, int C2, int EPI2, bool TADD, int NT1, int MS1, int NT2, int MS2, int WD2, int NPA, int NPB>
 __global__ __launch_bounds__(WG, 2) void fused2_kernel(FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -307,19 +446,49 @@ __global__ __launch_bounds__(WG, 2) void fused2_kernel(FusedArgs a)
     constexpr int CAT = MODE1 == M1_FIRST ? 8 : CA, CBT = MODE1 == M1_UPCAT ? CB : 8;
     (void)SA; (void)SB; (void)SO;
     const int64_t total = a.B * a.nbands;
+#ifdef IDM_TIMELINE
+    constexpr int TLK = MODE1 == M1_FIRST ? 0 : MODE1 == M1_PLAIN ? (CA == 32 ? 1 : 2) : (CA == 128 ? 3 : 4);
+    int tl_it = 0;
+#endif
 
-    // LDS map: [input region | mid tile]; the output staging / score buffer reuses the input region.
+    // LDS map: [input region | mid tile | epilogue constants]; the output staging / score buffer
+    // reuses the input region.
     char *lds_in = smem;
     char *lds_mid = smem + a.lds_in_bytes;
     char *tile_a = lds_in;
     char *tile_b = MODE1 == M1_UPCAT ? lds_in + ((((R >> 1) + 2) * ((W >> 1) + 2) * SA + 15) & ~15) : nullptr;
+    constexpr int NCONST = 2 * C1 + 2 * C2 + 4;
+    float *cst = (float *)(smem + a.lds_in_bytes + a.lds_mid_bytes) - NCONST;
+    const float *c_b1 = cst, *c_t1 = cst + C1, *c_b2 = cst + 2 * C1, *c_wh = c_b2 + C2, *c_bh = c_b2 + 2 * C2;
+    (void)c_t1; (void)c_wh; (void)c_bh;
+    for (int i = tid; i < C1; i += WG) {
+        cst[i] = a.b1[i];
+        cst[C1 + i] = TADD ? a.tadd1[i] : 0.0f;
+    }
+    for (int i = tid; i < C2; i += WG) {
+        cst[2 * C1 + i] = a.b2[i];
+        cst[2 * C1 + C2 + i] = EPI2 == E2_HEAD ? a.w_head[i] : 0.0f;
+    }
+    if (tid == 0) cst[2 * C1 + 2 * C2] = EPI2 == E2_HEAD ? a.b_head[0] : 0.0f;
+
+    const LaneGeo geo = make_geo(W, lane & 31);
+    using Conv1 = ConvStage<MODE1 == M1_FIRST ? 16 : CA, MODE1 == M1_UPCAT ? CB : 0, MODE1 == M1_UPCAT, C1, NT1, MS1, 3, TADD>;
+    using Conv2 = ConvStage<C1, 0, false, C2, NT2, MS2, WD2, EPI2 == E2_HEAD>;
+    constexpr bool EARLY_PF = Conv2::FULL;  // conv2 never waits on vector memory: request the next band before it
+    Conv1 cs1;
+    Conv2 cs2;
+    (void)cs1;
 
     TileRegs<CAT, MODE1 == M1_FIRST ? 1 : NPA> ra;
     TileRegs<CBT, MODE1 == M1_UPCAT ? NPB : 1> rb;
     float rx[MODE1 == M1_FIRST ? NPA : 1];
     (void)ra; (void)rb; (void)rx;
 
+    // (the thread index is made opaque per call: otherwise the per-item index arithmetic of the
+    // tile copies is hoisted out of the band loop and held in registers across the convolutions)
     auto pf_load = [&](int64_t wg) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
         const int64_t b = wg / a.nbands;
         const int y0 = (int)(wg - b * a.nbands) * R;
         if constexpr (MODE1 == M1_FIRST) {
@@ -338,6 +507,8 @@ __global__ __launch_bounds__(WG, 2) void fused2_kernel(FusedArgs a)
         }
     };
     auto pf_store = [&]() {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
         if constexpr (MODE1 == M1_FIRST) {
             float *xs = (float *)lds_in;
 #pragma unroll
@@ -354,130 +525,159 @@ __global__ __launch_bounds__(WG, 2) void fused2_kernel(FusedArgs a)
         }
     };
 
+    // HEAD: the state update works on float4 quads (one Philox counter each), spread over the four
+    // wavefronts; quad q of a band -> wavefront q / qpw, lane q % qpw.
+    struct Quad { int64_t off; int qs; bool act, path; };
+    auto quad_of = [&](int64_t wg) {
+        Quad q;
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
+        const int64_t b = wg / a.nbands;
+        const int y0 = (int)(wg - b * a.nbands) * R;
+        const int rowsx = min(min(R, H - y0), a.Hx - y0);
+        const int qrow = a.Wx >> 2, nq = max(rowsx, 0) * qrow, qpw = (nq + 3) >> 2;
+        q.path = (a.Wx & 3) == 0 && qpw <= 64;
+        const int qi = wave * qpw + lane;
+        q.act = q.path && lane < qpw && qi < nq;
+        const int qr = qi / max(qrow, 1), qx = qi - qr * qrow;
+        q.qs = qr * W + qx * 4;                                        // offset in the LDS score tile
+        q.off = (int64_t)b * a.Hx * a.Wx + (y0 + qr) * a.Wx + qx * 4;  // offset in x / score / noise
+        return q;
+    };
+    f32x4 x_next = {0.f, 0.f, 0.f, 0.f};
+    auto x_fetch = [&](int64_t wg) {
+        if constexpr (EPI2 == E2_HEAD) {
+            const Quad q = quad_of(wg);
+            if (q.act && a.do_update) x_next = *(const f32x4 *)(a.x + q.off);
+        }
+    };
+    auto band_geo = [&](int64_t wg, int &y0, int &rlo, int &rhi) {
+        const int64_t b = wg / a.nbands;
+        y0 = (int)(wg - b * a.nbands) * R;
+        rlo = y0 == 0 ? 1 : 0;
+        rhi = min(R + 2, H - y0 + 1);
+    };
+    auto conv1_begin = [&](int64_t wg) {
+        if constexpr (MODE1 != M1_FIRST) {
+            int y0, rlo, rhi;
+            band_geo(wg, y0, rlo, rhi);
+            cs1.begin(tile_a, tile_b, c_b1, c_t1, geo, rlo, rhi - rlo, (const bf16x8 *)a.w1, wave, lane);
+        }
+    };
+
     clear_halo<C1>(lds_mid, W, R + 2, 0, 0, tid);  // halo columns of the mid tile: never written afterwards
     int64_t wg = blockIdx.x;
-    if (wg < total) pf_load(wg);
+    if (wg < total) {
+        conv1_begin(wg);
+        x_fetch(wg);
+        pf_load(wg);
+    }
 
     for (; wg < total; wg += gridDim.x) {
         const int64_t b = wg / a.nbands;
-        const int y0 = (int)(wg - b * a.nbands) * R;
-        const int rlo = y0 == 0 ? 1 : 0;
-        const int rhi = min(R + 2, H - y0 + 1);
+        int y0, rlo, rhi;
+        band_geo(wg, y0, rlo, rhi);
+        const f32x4 x_cur = x_next;
+        (void)x_cur;
 
+        TL(0);
+        TL(9);
         pf_store();
         // rows of the mid tile outside the map are conv2's zero padding (an earlier band may have left data there)
         if (rlo) clear_halo<C1>(lds_mid, W, 0, 0, 1, tid);
         if (rhi < R + 2) clear_halo<C1>(lds_mid, W, 0, rhi, R + 2, tid);
+        TL(1);
         __syncthreads();
+        TL(2);
 
         // ---- conv1 on rows y0-1 .. y0+R (clipped to the map) -> mid tile row (g - (y0-1)) ----
         {
-            const int npix = (rhi - rlo) * W;
-            auto epi1 = [&](const f32x16 &acc, int mt, int r, int x, bool valid) {
+            auto epi1 = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *kt, int mt, int r, int x, bool valid) {
                 if (!valid) return;
-                char *dst = lds_mid + (r * (W + 2) + x + 1) * SM;
+                char *dst = lds_mid + (r * (W + 2) + x + 1) * SM + (mt * 32 + 4 * h) * 2;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int co = mt * 32 + 8 * g + 4 * h;
-                    const f32x4 bv = *(const f32x4 *)(a.b1 + co);
-                    float z[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) z[j] = acc[4 * g + j] + bv[j];
-                    if (a.s1) {
-                        const f32x4 sv = *(const f32x4 *)(a.s1 + co), hv = *(const f32x4 *)(a.h1 + co);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) z[j] = z[j] * sv[j] + hv[j];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) z[j] = fsilu(z[j]);
-                    if (a.tadd1) {
-                        const f32x4 tv = *(const f32x4 *)(a.tadd1 + co);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) z[j] += tv[j];
-                    }
-                    *(bf16x4 *)(dst + co * 2) = pack4(z[0], z[1], z[2], z[3]);
+                    f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                    z = silu4(z + kb[g]);
+                    if constexpr (TADD) z = z + kt[g];
+                    *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
                 }
             };
             if constexpr (MODE1 == M1_FIRST)
-                conv_first_stage((const float *)lds_in, W, rlo, npix, (const bf16x8 *)a.w1, wave, lane, epi1);
+                conv_first_stage((const float *)lds_in, c_b1, W, rlo, (rhi - rlo) * W, (const bf16x8 *)a.w1, wave, lane, epi1);
             else
-                conv_stage<CA, CB, MODE1 == M1_UPCAT, C1, NT1, MS1>(tile_a, tile_b, W, rlo, npix, (const bf16x8 *)a.w1,
-                                                                    wave, lane, epi1);
+                cs1.run(epi1);
         }
-        __syncthreads();
+        TL(3);
 
         // ---- conv2 on rows y0 .. y0+R-1 (clipped) ----
         const int rows2 = min(R, H - y0);
         const int npix2 = rows2 * W;
         // the last iteration reloads its own band (discarded): an unconditional load keeps the prefetch
-        // registers dead across conv1/conv2 instead of loop-carried
+        // registers dead across the convolutions instead of loop-carried
         const int64_t wg_next = wg + gridDim.x < total ? wg + gridDim.x : wg;
+        cs2.begin(lds_mid, nullptr, c_b2, c_wh, geo, 0, rows2, (const bf16x8 *)a.w2, wave, lane);
+        if constexpr (EARLY_PF) {
+            x_fetch(wg_next);
+            pf_load(wg_next);
+        }
+        __syncthreads();
+        TL(4);
         if constexpr (EPI2 == E2_HEAD) {
             float *score_s = (float *)lds_in;  // rows2 * W floats
-            auto epi2 = [&](const f32x16 &acc, int mt, int r, int x, bool valid) {
+            auto epi2 = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *kw, int mt, int r, int x, bool valid) {
                 (void)mt;
-                float part = 0.0f;
+                f32x4 p4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int co = 8 * g + 4 * h;
-                    const f32x4 bv = *(const f32x4 *)(a.b2 + co), wv = *(const f32x4 *)(a.w_head + co);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float z = acc[4 * g + j] + bv[j];
-                        if (a.s2) z = z * a.s2[co + j] + a.h2[co + j];
-                        part += fsilu(z) * wv[j];
-                    }
+                    f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                    p4 += silu4(z + kb[g]) * kw[g];
                 }
+                float part = (p4[0] + p4[1]) + (p4[2] + p4[3]);
                 part += __shfl_xor(part, 32, 64);
-                if (valid && h == 0) score_s[r * W + x] = part + a.b_head[0];
+                if (valid && h == 0) score_s[r * W + x] = part + c_bh[0];
             };
-            conv_stage<C1, 0, false, C2, NT2, MS2>(lds_mid, nullptr, W, 0, npix2, (const bf16x8 *)a.w2, wave, lane, epi2);
-
-            // This band's x is fetched BEFORE the next band's input: vector-memory results return in
-            // issue order, so the update below then never waits for the prefetch.
-#ifdef IDM_ABL_NOOUT
-            const int rowsx = tid == 999 ? 1 : 0;
-#else
-            const int rowsx = min(rows2, a.Hx - y0);
-#endif
-            float *xg = a.x + (size_t)b * a.Hx * a.Wx;
-            const size_t lat_off = (size_t)b * a.Hx * a.Wx;
-            const int qrow = a.Wx >> 2;
-            const bool quad_path = (a.Wx & 3) == 0 && rowsx * qrow <= WG;
-            const int qr = tid / max(qrow, 1), qx = tid - qr * qrow;
-            const int qe = (y0 + qr) * a.Wx + qx * 4;
-            const bool qact = quad_path && tid < rowsx * qrow;
-            f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-            if (qact && a.do_update) xv = *(const f32x4 *)(xg + qe);
-            pf_load(wg_next);
+            cs2.run(epi2);
+            TL(5);
+            conv1_begin(wg_next);
+            if constexpr (!EARLY_PF) {
+                x_fetch(wg_next);
+                pf_load(wg_next);
+            }
             __syncthreads();
-            if (quad_path) {
-                if (qact) {
-                    f32x4 sc;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) sc[j] = score_s[qr * W + qx * 4 + j];
-                    if (a.score_out) *(f32x4 *)(a.score_out + lat_off + qe) = sc;
+            TL(6);
+
+            const Quad q = quad_of(wg);
+            if (q.path) {
+                if (q.act) {
+                    f32x4 sc = *(const f32x4 *)(score_s + q.qs);
+                    if (a.score_out) *(f32x4 *)(a.score_out + q.off) = sc;
                     if (a.do_update) {
                         float z[4] = {0.f, 0.f, 0.f, 0.f};
                         if (a.add_noise) {
                             if (a.noise) {
-                                const f32x4 zv = *(const f32x4 *)(a.noise + lat_off + qe);
+                                const f32x4 zv = *(const f32x4 *)(a.noise + q.off);
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) z[j] = zv[j];
                             } else {
-                                normal4(a.ph.seed, a.ph.first_global_index + b, (uint32_t)(qe >> 2), a.ph.t, z);
+                                const int64_t lat = (int64_t)b * a.Hx * a.Wx;
+                                normal4(a.ph.seed, a.ph.first_global_index + b, (uint32_t)((q.off - lat) >> 2), a.ph.t, z);
                             }
                         }
+                        f32x4 xv = x_cur;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             float v = __fadd_rn(__fmul_rn(a.c1, xv[j]), __fmul_rn(a.beta, sc[j]));
                             if (a.add_noise) v = __fadd_rn(v, __fmul_rn(z[j], a.sd));
                             xv[j] = v;
                         }
-                        *(f32x4 *)(xg + qe) = xv;
+                        *(f32x4 *)(a.x + q.off) = xv;
                     }
                 }
             } else {
+                const int rowsx = min(rows2, a.Hx - y0);
+                float *xg = a.x + (size_t)b * a.Hx * a.Wx;
+                const size_t lat_off = (size_t)b * a.Hx * a.Wx;
                 for (int i = tid; i < rowsx * a.Wx; i += WG) {
                     const int r = i / a.Wx, xc = i - r * a.Wx;
                     const int e = (y0 + r) * a.Wx + xc;
@@ -500,34 +700,24 @@ __global__ __launch_bounds__(WG, 2) void fused2_kernel(FusedArgs a)
             }
         } else {
             char *stage = lds_in;  // [rows2][W] positions of SO bytes
-            auto epi2 = [&](const f32x16 &acc, int mt, int r, int x, bool valid) {
+            auto epi2 = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *, int mt, int r, int x, bool valid) {
                 if (!valid) return;
-                char *dst = stage + (r * W + x) * SO;
+                char *dst = stage + (r * W + x) * SO + (mt * 32 + 4 * h) * 2;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int co = mt * 32 + 8 * g + 4 * h;
-                    const f32x4 bv = *(const f32x4 *)(a.b2 + co);
-                    float z[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) z[j] = acc[4 * g + j] + bv[j];
-                    if (a.s2) {
-                        const f32x4 sv = *(const f32x4 *)(a.s2 + co), hv = *(const f32x4 *)(a.h2 + co);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) z[j] = z[j] * sv[j] + hv[j];
-                    }
-                    *(bf16x4 *)(dst + co * 2) = pack4(fsilu(z[0]), fsilu(z[1]), fsilu(z[2]), fsilu(z[3]));
+                    f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                    z = silu4(z + kb[g]);
+                    *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
                 }
             };
-            conv_stage<C1, 0, false, C2, NT2, MS2>(lds_mid, nullptr, W, 0, npix2, (const bf16x8 *)a.w2, wave, lane, epi2);
-            // next band's input: issued after this wave's last weight wait, so the HBM latency overlaps
-            // the copy-out instead of stalling the weight pipeline (vector-memory results return in order)
-            pf_load(wg_next);
+            cs2.run(epi2);
+            TL(5);
+            conv1_begin(wg_next);
+            if constexpr (!EARLY_PF) pf_load(wg_next);
             __syncthreads();
+            TL(6);
             constexpr int CH = C2 / 8;
             __bf16 *og = (__bf16 *)a.out + ((size_t)b * H + y0) * W * C2;
-#ifdef IDM_ABL_NOOUT
-            if (tid == 999)
-#endif
             for (int i = tid; i < npix2 * CH; i += WG) {
                 const int ch = i % CH, pos = i / CH;
                 *(bf16x8 *)(og + (size_t)pos * C2 + ch * 8) = *(const bf16x8 *)(stage + pos * SO + ch * 16);
@@ -549,7 +739,12 @@ __global__ __launch_bounds__(WG, 2) void fused2_kernel(FusedArgs a)
                 }
             }
         }
+        TL(7);
         __syncthreads();  // staging / score consumed before the next band's input overwrites the region
+        TL(8);
+#ifdef IDM_TIMELINE
+        ++tl_it;
+#endif
     }
 }
 
@@ -592,44 +787,51 @@ void fused_lds_bytes(int kind, int W, int R, int *in_bytes, int *mid_bytes)
     else in = align16((R / 2 + 2) * (W / 2 + 2) * sa) + (R + 4) * (W + 2) * sb;
     const int stage = k.epi2 == E2_HEAD ? R * W * 4 : R * W * so;
     *in_bytes = align16(in > stage ? in : stage);
-    *mid_bytes = align16((R + 2) * (W + 2) * sm);
+    // mid tile, then the epilogue constants (2*C1 + 2*C2 + 4 floats)
+    *mid_bytes = align16((R + 2) * (W + 2) * sm) + (2 * k.c1 + 2 * k.c2 + 4) * 4;
 }
 
+// Launch state per kernel instance (all instances share one function-pointer type, so the
+// state cannot live in a function-local static of the launcher template).
+struct LaunchState {
+    bool configured = false;
+    int cus = 0, cached_lds = -1, cached_blocks = 0;
+};
+
 template <class K>
-static hipError_t launch_one(K kernel, const FusedArgs &a, int64_t B, hipStream_t s)
+static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int64_t B, hipStream_t s)
 {
     const int lds = a.lds_in_bytes + a.lds_mid_bytes;
-    static thread_local bool configured = false;
-    static thread_local int cus = 0, cached_lds = -1, cached_blocks = 0;
-    if (!configured) {
+    if (!st.configured) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         int dev = 0;
         hipDeviceProp_t prop;
         if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
-        cus = prop.multiProcessorCount;
-        configured = true;
+        st.cus = prop.multiProcessorCount;
+        st.configured = true;
     }
-    if (cached_lds != lds) {
+    if (st.cached_lds != lds) {
         int n = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kernel, WG, (size_t)lds);
         if (e != hipSuccess) return e;
-        cached_blocks = n > 0 ? n : 1;
-        cached_lds = lds;
+        st.cached_blocks = n > 0 ? n : 1;
+        st.cached_lds = lds;
     }
     const int64_t total = B * a.nbands;
-    const int64_t grid = std::min<int64_t>(total, (int64_t)cus * cached_blocks);
+    const int64_t grid = std::min<int64_t>(total, (int64_t)st.cus * st.cached_blocks);
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WG), lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
 {
+    static thread_local LaunchState st[5];
     switch (kind) {
-    case FK_A: return launch_one(fused2_kernel<M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, 1, 1, 2, 1, 2, 0>, a, B, s);
-    case FK_M1: return launch_one(fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, 2, 2, 2, 2, 5, 0>, a, B, s);
-    case FK_M2: return launch_one(fused2_kernel<M1_PLAIN, 64, 0, 128, 128, E2_STORE, 2, 1, 2, 1, 3, 0>, a, B, s);
-    case FK_M3: return launch_one(fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, 3, 1, 2, 1, 3, 6>, a, B, s);
-    default: return launch_one(fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, 3, 1, 2, 1, 3, 6>, a, B, s);
+    case FK_A: return launch_one(st[0], fused2_kernel<M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, false, 1, 1, 2, 1, 6, 2, 0>, a, B, s);
+    case FK_M1: return launch_one(st[1], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, 3, 1, 2, 1, 3, 5, 0>, a, B, s);
+    case FK_M2: return launch_one(st[2], fused2_kernel<M1_PLAIN, 64, 0, 128, 128, E2_STORE, true, 2, 1, 2, 1, 3, 3, 0>, a, B, s);
+    case FK_M3: return launch_one(st[3], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, 3, 1, 2, 1, 3, 3, 6>, a, B, s);
+    default: return launch_one(st[4], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, 3, 1, 2, 1, 3, 3, 6>, a, B, s);
     }
 }

@@ -76,9 +76,9 @@ struct FusedArgs {
     const void *in_a;  // PLAIN: (B,H,W,CA); UPCAT: (B,H/2,W/2,CA); FIRST: x float32 (B,Hx,Wx)
     const void *in_b;  // UPCAT: (B,H,W,CB)
     const void *w1;
-    const float *b1, *s1, *h1, *tadd1;
+    const float *b1, *tadd1;   // bias; per-channel add after the activation (FK_M2 only)
     const void *w2;
-    const float *b2, *s2, *h2;
+    const float *b2;
     void *out;         // STORE*: (B,H,W,C2) bf16
     void *out_pool;    // STORE_POOL: (B,H/2,W/2,C2) bf16
     // HEAD

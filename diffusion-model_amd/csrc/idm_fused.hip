@@ -435,11 +435,13 @@ extern "C" int idm_debug_timeline(long long *host)
 //     conv2 -> [weights of the next band's conv1] -> [next band's input into registers] -> copy-out
 // and, where conv2's weights fit in registers as a whole (WD2 >= its supersteps), the next band's
 // input is requested even before conv2.
-template <int MODE1, int CA, int CB, int C1, int C2, int EPI2, bool TADD, int NT1, int MS1, int NT2, int MS2, int WD2, int NPA, int NPB>
-__global__ __launch_bounds__(WG, 2) void fused2_kernel(FusedArgs a)
+// OCC: wavefronts per SIMD the register budget is sized for (= workgroups per CU when LDS allows).
+template <int MODE1, int CA, int CB, int C1, int C2, int EPI2, bool TADD, int NT1, int MS1, int WD1, int NT2, int MS2, int WD2, int NPA, int NPB, int OCC>
+__global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = tid >> 6;
     const int h = lane >> 5;
     const int W = a.W, H = a.H, R = a.R;
     constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16, SM = C1 * 2 + 16, SO = C2 * 2 + 16;
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(WG, 2) void fused2_kernel(FusedArgs a)
     if (tid == 0) cst[2 * C1 + 2 * C2] = EPI2 == E2_HEAD ? a.b_head[0] : 0.0f;
 
     const LaneGeo geo = make_geo(W, lane & 31);
-    using Conv1 = ConvStage<MODE1 == M1_FIRST ? 16 : CA, MODE1 == M1_UPCAT ? CB : 0, MODE1 == M1_UPCAT, C1, NT1, MS1, 3, TADD>;
+    using Conv1 = ConvStage<MODE1 == M1_FIRST ? 16 : CA, MODE1 == M1_UPCAT ? CB : 0, MODE1 == M1_UPCAT, C1, NT1, MS1, WD1, TADD>;
     using Conv2 = ConvStage<C1, 0, false, C2, NT2, MS2, WD2, EPI2 == E2_HEAD>;
     constexpr bool EARLY_PF = Conv2::FULL;  // conv2 never waits on vector memory: request the next band before it
     Conv1 cs1;
@@ -525,8 +527,9 @@ __global__ __launch_bounds__(WG, 2) void fused2_kernel(FusedArgs a)
         }
     };
 
-    // HEAD: the state update works on float4 quads (one Philox counter each), spread over the four
-    // wavefronts; quad q of a band -> wavefront q / qpw, lane q % qpw.
+    // HEAD: the state update works on float4 quads (one Philox counter each).  The quads of a band
+    // are dealt to the wavefronts with the fewest conv1 rows (all four when the split is even):
+    // those draw the band's noise right after their conv1 share, while the others still compute.
     struct Quad { int64_t off; int qs; bool act, path; };
     auto quad_of = [&](int64_t wg) {
         Quad q;
@@ -534,11 +537,27 @@ __global__ __launch_bounds__(WG, 2) void fused2_kernel(FusedArgs a)
         asm volatile("" : "+v"(lane));
         const int64_t b = wg / a.nbands;
         const int y0 = (int)(wg - b * a.nbands) * R;
+        const int rlo = y0 == 0 ? 1 : 0, rhi = min(R + 2, H - y0 + 1);
+        const int tot = Conv1::NSL * geo.ncb * ((rhi - rlo + geo.TR - 1) / geo.TR);
+        int len[4], mn = 1 << 30;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            len[w] = (((w + 1) * tot) >> 2) - ((w * tot) >> 2);
+            mn = min(mn, len[w]);
+        }
+        int nl = 0, lr = 0, mine = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int light = len[w] == mn;
+            lr += light && w < wave;
+            mine |= light && w == wave;
+            nl += light;
+        }
         const int rowsx = min(min(R, H - y0), a.Hx - y0);
-        const int qrow = a.Wx >> 2, nq = max(rowsx, 0) * qrow, qpw = (nq + 3) >> 2;
+        const int qrow = a.Wx >> 2, nq = max(rowsx, 0) * qrow, qpw = (nq + nl - 1) / nl;
         q.path = (a.Wx & 3) == 0 && qpw <= 64;
-        const int qi = wave * qpw + lane;
-        q.act = q.path && lane < qpw && qi < nq;
+        const int qi = lr * qpw + lane;
+        q.act = q.path && mine && lane < qpw && qi < nq;
         const int qr = qi / max(qrow, 1), qx = qi - qr * qrow;
         q.qs = qr * W + qx * 4;                                        // offset in the LDS score tile
         q.off = (int64_t)b * a.Hx * a.Wx + (y0 + qr) * a.Wx + qx * 4;  // offset in x / score / noise
@@ -608,6 +627,16 @@ __global__ __launch_bounds__(WG, 2) void fused2_kernel(FusedArgs a)
             else
                 cs1.run(epi1);
         }
+        float zq[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI2 == E2_HEAD) {
+            if (a.do_update && a.add_noise && !a.noise) {
+                const Quad q = quad_of(wg);
+                if (q.act) {
+                    const int64_t lat = (int64_t)b * a.Hx * a.Wx;
+                    normal4(a.ph.seed, a.ph.first_global_index + b, (uint32_t)((q.off - lat) >> 2), a.ph.t, zq);
+                }
+            }
+        }
         TL(3);
 
         // ---- conv2 on rows y0 .. y0+R-1 (clipped) ----
@@ -653,16 +682,11 @@ __global__ __launch_bounds__(WG, 2) void fused2_kernel(FusedArgs a)
                     f32x4 sc = *(const f32x4 *)(score_s + q.qs);
                     if (a.score_out) *(f32x4 *)(a.score_out + q.off) = sc;
                     if (a.do_update) {
-                        float z[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (a.add_noise) {
-                            if (a.noise) {
-                                const f32x4 zv = *(const f32x4 *)(a.noise + q.off);
+                        float z[4] = {zq[0], zq[1], zq[2], zq[3]};
+                        if (a.add_noise && a.noise) {
+                            const f32x4 zv = *(const f32x4 *)(a.noise + q.off);
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) z[j] = zv[j];
-                            } else {
-                                const int64_t lat = (int64_t)b * a.Hx * a.Wx;
-                                normal4(a.ph.seed, a.ph.first_global_index + b, (uint32_t)((q.off - lat) >> 2), a.ph.t, z);
-                            }
+                            for (int j = 0; j < 4; ++j) z[j] = zv[j];
                         }
                         f32x4 xv = x_cur;
 #pragma unroll
@@ -824,14 +848,31 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
     return hipGetLastError();
 }
 
+// Tunables per kernel: NT1, MS1, WD1, NT2, MS2, WD2, NPA, NPB, OCC (overridable at build time for tuning runs).
+#ifndef IDM_CFG_A
+#define IDM_CFG_A 1, 1, 3, 2, 1, 6, 2, 0, 3
+#endif
+#ifndef IDM_CFG_M1
+#define IDM_CFG_M1 3, 1, 3, 2, 1, 3, 5, 0, 2
+#endif
+#ifndef IDM_CFG_M2
+#define IDM_CFG_M2 2, 1, 3, 2, 1, 3, 3, 0, 2
+#endif
+#ifndef IDM_CFG_M3
+#define IDM_CFG_M3 3, 1, 3, 2, 1, 3, 3, 6, 2
+#endif
+#ifndef IDM_CFG_B
+#define IDM_CFG_B 3, 1, 3, 2, 1, 3, 3, 6, 2
+#endif
+
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
 {
     static thread_local LaunchState st[5];
     switch (kind) {
-    case FK_A: return launch_one(st[0], fused2_kernel<M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, false, 1, 1, 2, 1, 6, 2, 0>, a, B, s);
-    case FK_M1: return launch_one(st[1], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, 3, 1, 2, 1, 3, 5, 0>, a, B, s);
-    case FK_M2: return launch_one(st[2], fused2_kernel<M1_PLAIN, 64, 0, 128, 128, E2_STORE, true, 2, 1, 2, 1, 3, 3, 0>, a, B, s);
-    case FK_M3: return launch_one(st[3], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, 3, 1, 2, 1, 3, 3, 6>, a, B, s);
-    default: return launch_one(st[4], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, 3, 1, 2, 1, 3, 3, 6>, a, B, s);
+    case FK_A: return launch_one(st[0], fused2_kernel<M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, false, IDM_CFG_A>, a, B, s);
+    case FK_M1: return launch_one(st[1], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1>, a, B, s);
+    case FK_M2: return launch_one(st[2], fused2_kernel<M1_PLAIN, 64, 0, 128, 128, E2_STORE, true, IDM_CFG_M2>, a, B, s);
+    case FK_M3: return launch_one(st[3], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, IDM_CFG_M3>, a, B, s);
+    default: return launch_one(st[4], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, IDM_CFG_B>, a, B, s);
     }
 }

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Builds tuning variants of the fused kernels: each argument is "name:-DIDM_CFG_X=... [-D...]".
+# The libraries land in diffusion-model_amd/isingdiff/abl/lib_<name>.so (git-ignored).
+set -e
+cd "$(dirname "$0")/../diffusion-model_amd/csrc"
+mkdir -p ../isingdiff/abl
+find ../isingdiff/abl -name "lib_*.so" ! -name "lib_0base.so" -delete
+n=0
+for spec in "$@"; do
+  name="${spec%%:*}"; flags="${spec#*:}"
+  n=$((n + 1)); [ $((n % 4)) -eq 0 ] && wait
+  ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c idm_fused.hip -o /tmp/var_$name.o &&
+    hipcc --offload-arch=gfx950 -shared -fPIC -o ../isingdiff/abl/lib_$name.so idm_api.o idm_canon.o idm_fast.o /tmp/var_$name.o || echo "FAILED $name" ) &
+done
+wait
+ls ../isingdiff/abl

@@ -31,26 +31,38 @@ FLOP_PER_SITE_FORWARD = 221824.0      # 2*MACs of the 11 Conv2D layers per latti
 PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA
 PEAK_FP32_TFLOPS = 157.3              # MI355X fp32 MFMA
 PEAK_HBM_GBS = 8000.0
+# HBM bytes per lattice per launch of the dominant kernel at L=32 (x, skip1 and the conv7 map in,
+# x out), from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes kept in profiles/r01/v2_pmc_hbm.txt
+# (FETCH_SIZE doubled: gfx950 counts 16-byte-per-lane streaming reads at half their bytes).
+PMC_HBM_BYTES_PER_LATTICE = {"fused_B(conv8,9,head,step)": 140.1 * 1024}
 
 
 def cpu_baseline(spec, L, T, betas, budget_s=20.0):
     """Time the CPU restatement on a bounded sample of the same workload (same L, same weights,
-    same update rule): B_s lattices for T_s of the T steps, scaled to whole-schedule lattices/s."""
+    same update rule).  A short probe sizes the sample to about `budget_s` seconds: the whole
+    schedule on as many lattices as fit, or, on a slow host, 32 lattices for part of the schedule
+    (then scaled to whole-schedule lattices/s)."""
     from oracle.ref_torch import TorchUNet, diffusion_backward
     threads = min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     model = TorchUNet(spec)
     rs = np.random.RandomState(42)
-    B_s, T_probe = 32, 4
+    B_p, T_probe = 32, 4
+    xp = rs.standard_normal((B_p, L, L, spec.channels)).astype(np.float32)
+    draw = lambda shape: (lambda t: rs.standard_normal(shape).astype(np.float32))
+    diffusion_backward(model, xp, betas[-T_probe:], T_probe, draw(xp.shape))            # warm-up
+    t0 = time.perf_counter()
+    diffusion_backward(model, xp, betas[-T_probe:], T_probe, draw(xp.shape))
+    per_lattice_step = (time.perf_counter() - t0) / (T_probe * B_p)
+    if per_lattice_step * B_p * T <= budget_s:
+        T_s = T
+        B_s = int(min(1024, max(B_p, budget_s / (per_lattice_step * T)))) // 16 * 16
+    else:
+        B_s = B_p
+        T_s = int(max(8, budget_s / (per_lattice_step * B_p)))
     x = rs.standard_normal((B_s, L, L, spec.channels)).astype(np.float32)
-    noise = lambda t: rs.standard_normal(x.shape).astype(np.float32)
-    diffusion_backward(model, x, betas[-T_probe:], T_probe, noise)            # warm-up + probe
     t0 = time.perf_counter()
-    diffusion_backward(model, x, betas[-T_probe:], T_probe, noise)
-    per_step = (time.perf_counter() - t0) / T_probe
-    T_s = int(max(8, min(T, budget_s / max(per_step, 1e-6))))
-    t0 = time.perf_counter()
-    diffusion_backward(model, x, betas[-T_s:], T_s, noise)
+    diffusion_backward(model, x, betas[-T_s:], T_s, draw(x.shape))
     dt = time.perf_counter() - t0
     value = B_s / (dt * T / T_s)
     return {"value": value, "unit": "lattices/s", "cores": threads, "kind": "port",
@@ -141,8 +153,11 @@ def main():
             dom = max(prof, key=lambda e: e["ms"])
             if dom["flop"] > 0:
                 ach = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
+                per_lat = PMC_HBM_BYTES_PER_LATTICE.get(dom["name"]) if L == 32 else None
+                lat_per_launch = B * args.steps * 1.0 / (dom["launches"] / T)
                 roof = {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                        "frac": ach / peak, "traffic": None,
+                        "frac": ach / peak, "traffic": per_lat * lat_per_launch if per_lat else None,
+                        "traffic_unit": "HBM bytes per launch (PMC, profiles/r01/v2_pmc_hbm.txt)",
                         "flop_per_launch": dom["flop"] / dom["launches"], "avg_launch_us": 1e3 * dom["ms"] / dom["launches"],
                         "share_of_gpu_time": dom["ms"] / tot_ms}
             else:

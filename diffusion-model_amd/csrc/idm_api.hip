@@ -86,6 +86,10 @@ std::vector<uint16_t> pack_first_bf16(const float *w, int cout)
 
 }  // namespace
 
+int idm_set_error(int code, const char *msg) { return fail(code, msg ? msg : ""); }
+
+std::vector<float> idm_pack_weights_f32(const float *w, int cin, int cout) { return pack_weights_f32(w, cin, cout); }
+
 struct idm_model {
     int device = 0;
     int C = 1, F = 32;

@@ -1,0 +1,509 @@
+// MNIST bit-flip diffusion sampler (mnist_diffusion/mnist_diffusion.py:43-52, :162-240) in the
+// canonical float32 arithmetic (parity mode): residual UNet with GroupNorm, time vectors from a
+// host-supplied sinusoidal embedding, XOR update with counter-based uniforms.
+//
+// Canonical order, in addition to the rules of idm_canon.hip: GroupNorm sums are 64 strided
+// partial sums (element e = pixel*Cg + channel-in-group goes to partial e % 64, ascending e)
+// folded by an xor butterfly 32,16,...,1; variance from fmaf(d,d,.) of centred values; rsqrt by
+// a fixed bit-trick + 4 Newton steps; y = (x*a) + b with a = inv*gamma, b = (-mean*a) + beta.
+// This file must be compiled with -ffp-contract=off.
+#include "../../include/isingdiff.h"
+#include "idm_internal.h"
+#include "idm_device.h"
+#include "idm_canon_math.h"
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int NBLK = 5;
+constexpr int kCin[NBLK] = {32, 32, 64, 192, 96};
+constexpr int kWidth[NBLK] = {32, 64, 128, 64, 32};
+constexpr int EMB = 32, TEMB = 128, TVEC = 320;
+
+DEVI float rsqrt_canon(float v)
+{
+    float r = __uint_as_float(0x5f3759dfu - (__float_as_uint(v) >> 1));
+    const float h = __fmul_rn(0.5f, v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float t = __fmul_rn(r, r);
+        t = __fmaf_rn(-h, t, 1.5f);
+        r = __fmul_rn(r, t);
+    }
+    return r;
+}
+
+struct TimeW {
+    const float *d1_w, *d1_b, *d2_w, *d2_b;
+    const float *t_w[NBLK], *t_b[NBLK];
+};
+
+// One block per embedding row: Dense(128,swish) -> Dense(128,swish) -> five Dense(width_i,swish).
+__global__ __launch_bounds__(128) void bf_time_kernel(const float *__restrict__ emb, TimeW w, float *__restrict__ out)
+{
+    __shared__ float e[EMB], a[TEMB], b[TEMB];
+    const int j = threadIdx.x;
+    const float *row = emb + (size_t)blockIdx.x * EMB;
+    if (j < EMB) e[j] = row[j];
+    __syncthreads();
+    float acc = 0.0f;
+    for (int i = 0; i < EMB; ++i) acc = __fmaf_rn(e[i], w.d1_w[i * TEMB + j], acc);
+    a[j] = csilu(__fadd_rn(acc, w.d1_b[j]));
+    __syncthreads();
+    acc = 0.0f;
+    for (int i = 0; i < TEMB; ++i) acc = __fmaf_rn(a[i], w.d2_w[i * TEMB + j], acc);
+    b[j] = csilu(__fadd_rn(acc, w.d2_b[j]));
+    __syncthreads();
+    int o = 0;
+    for (int k = 0; k < NBLK; ++k) {
+        const int n = kWidth[k];
+        if (j < n) {
+            acc = 0.0f;
+            for (int i = 0; i < TEMB; ++i) acc = __fmaf_rn(b[i], w.t_w[k][i * n + j], acc);
+            out[(size_t)blockIdx.x * TVEC + o + j] = csilu(__fadd_rn(acc, w.t_b[k][j]));
+        }
+        o += n;
+    }
+}
+
+// Conv2D(32, kernel 1) on the 0/1 image (:207).
+__global__ __launch_bounds__(256) void bf_in_kernel(const uint8_t *__restrict__ x, const float *__restrict__ w,
+                                                    const float *__restrict__ b, float *__restrict__ out, int64_t npix)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix * 32) return;
+    const int c = (int)(i & 31);
+    out[i] = __fadd_rn(__fmaf_rn((float)x[i >> 5], w[c], 0.0f), b[c]);
+}
+
+// GroupNormalization(groups=8) statistics: one wavefront per (sample, group); writes the affine
+// pair (a, b) of every channel of the group: y = (x*a) + b.
+__global__ __launch_bounds__(256) void bf_gn_stats_kernel(const float *__restrict__ x, int64_t B, int HW, int C,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          float *__restrict__ ab)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= B * 8) return;
+    const int64_t b = wv >> 3;
+    const int g = (int)(wv & 7), Cg = C >> 3, N = HW * Cg;
+    const float *xb = x + (size_t)b * HW * C + g * Cg;
+    float s = 0.0f;
+    for (int e = lane; e < N; e += 64) s = __fadd_rn(s, xb[(size_t)(e / Cg) * C + e % Cg]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s = __fadd_rn(s, __shfl_xor(s, off, 64));
+    const float mean = __fdiv_rn(s, (float)N);
+    float q = 0.0f;
+    for (int e = lane; e < N; e += 64) {
+        const float d = __fsub_rn(xb[(size_t)(e / Cg) * C + e % Cg], mean);
+        q = __fmaf_rn(d, d, q);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q = __fadd_rn(q, __shfl_xor(q, off, 64));
+    const float var = __fdiv_rn(q, (float)N);
+    const float inv = rsqrt_canon(__fadd_rn(var, 1e-3f));
+    if (lane < Cg) {
+        const int c = g * Cg + lane;
+        const float a = __fmul_rn(inv, gamma[c]);
+        ab[((size_t)b * C + c) * 2] = a;
+        ab[((size_t)b * C + c) * 2 + 1] = __fadd_rn(__fmul_rn(-mean, a), beta[c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bf_gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ ab,
+                                                          float *__restrict__ y, int64_t n, int HW, int C)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const int64_t b = i / ((int64_t)HW * C);
+    const float a = ab[(b * C + c) * 2], sh = ab[(b * C + c) * 2 + 1];
+    y[i] = csilu(__fadd_rn(__fmul_rn(x[i], a), sh));
+}
+
+// out = (conv1x1(x) + bias) + h  (the ResBlock's projected shortcut, :188-192); w == nullptr: out = x + h.
+__global__ __launch_bounds__(256) void bf_shortcut_kernel(const float *__restrict__ x, int Cin, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, const float *__restrict__ h,
+                                                          float *__restrict__ out, int64_t npix, int Cout)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix * Cout) return;
+    if (!w) {
+        out[i] = __fadd_rn(x[i], h[i]);
+        return;
+    }
+    const int co = (int)(i % Cout);
+    const float *xp = x + (i / Cout) * Cin;
+    float acc = 0.0f;
+    for (int c = 0; c < Cin; ++c) acc = __fmaf_rn(xp[c], w[(size_t)c * Cout + co], acc);
+    out[i] = __fadd_rn(__fadd_rn(acc, bias[co]), h[i]);
+}
+
+__global__ __launch_bounds__(256) void bf_maxpool_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t B,
+                                                         int H, int W, int C)
+{
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * Ho * Wo * C) return;
+    const int c = (int)(i % C);
+    const int x = (int)((i / C) % Wo), y = (int)((i / ((int64_t)C * Wo)) % Ho);
+    const int64_t b = i / ((int64_t)C * Wo * Ho);
+    const float *p = in + ((b * H + 2 * y) * W + 2 * x) * C + c;
+    out[i] = fmaxf(fmaxf(p[0], p[C]), fmaxf(p[(size_t)W * C], p[(size_t)W * C + C]));
+}
+
+// out (B,2H,2W,Cu+Cs) = Concatenate([UpSampling2D(up), skip]) (:225-226, :230-231)
+__global__ __launch_bounds__(256) void bf_upcat_kernel(const float *__restrict__ up, const float *__restrict__ skip,
+                                                       float *__restrict__ out, int64_t B, int H, int W, int Cu, int Cs)
+{
+    const int C = Cu + Cs, Ho = 2 * H, Wo = 2 * W;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * Ho * Wo * C) return;
+    const int c = (int)(i % C);
+    const int x = (int)((i / C) % Wo), y = (int)((i / ((int64_t)C * Wo)) % Ho);
+    const int64_t b = i / ((int64_t)C * Wo * Ho);
+    out[i] = c < Cu ? up[((b * H + (y >> 1)) * W + (x >> 1)) * Cu + c] : skip[((b * Ho + y) * Wo + x) * Cs + (c - Cu)];
+}
+
+// Conv2D(1, kernel 1, sigmoid) (:236)
+__global__ __launch_bounds__(256) void bf_head_kernel(const float *__restrict__ r, const float *__restrict__ w,
+                                                      const float *__restrict__ bias, float *__restrict__ proba, int64_t npix)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    const float *p = r + i * 32;
+    float acc = 0.0f;
+    for (int c = 0; c < 32; ++c) acc = __fmaf_rn(p[c], w[c], acc);
+    acc = __fadd_rn(acc, bias[0]);
+    proba[i] = __fdiv_rn(1.0f, __fadd_rn(1.0f, cexp(-acc)));
+}
+
+// X ^= (u < p) (:49-50).  One thread per four pixels; u from the injected tensor or from
+// Philox4x32-10 with counter (quad, sample lo, sample hi, t) and the seed as key.
+__global__ __launch_bounds__(256) void bf_flip_kernel(uint8_t *__restrict__ x, const float *__restrict__ proba,
+                                                      const float *__restrict__ u_in, int64_t B, int HW, PhiloxArgs ph)
+{
+    const int nq = (HW + 3) >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * nq) return;
+    const int64_t b = i / nq;
+    const int q = (int)(i - b * nq);
+    float u[4];
+    if (!u_in) {
+        uint32_t r[4];
+        const int64_t g = ph.first_global_index + b;
+        philox4x32_10((uint32_t)q, (uint32_t)g, (uint32_t)((uint64_t)g >> 32), (uint32_t)ph.t, (uint32_t)ph.seed,
+                      (uint32_t)(ph.seed >> 32), r);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[j] = u01(r[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = q * 4 + j;
+        if (e >= HW) break;
+        const int64_t k = b * HW + e;
+        const float uu = u_in ? u_in[k] : u[j];
+        x[k] ^= (uint8_t)(uu < proba[k]);
+    }
+}
+
+inline unsigned blocks(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+struct idm_bitflip {
+    int device = 0;
+    const float *t[IDM_BITFLIP_NTENSOR] = {};   // device copies, Keras layouts
+    void *c1_pack[NBLK] = {}, *c2_pack[NBLK] = {};
+    float *emb_dev = nullptr;   // (T, EMB) scratch for the embedding rows
+    int emb_cap = 0;
+    float *tvec = nullptr;      // (T, TVEC)
+    int tvec_cap = 0;
+    char *ws = nullptr;
+    size_t ws_bytes = 0;
+    std::vector<void *> owned;
+};
+
+namespace {
+
+#define BFCHK(expr)                                                                                    \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return idm_set_error(IDM_ERR_HIP, (std::string(#expr) + ": " + hipGetErrorString(e_)).c_str()); \
+    } while (0)
+
+int bf_upload(idm_bitflip *m, const float *host, size_t n, float **dev)
+{
+    BFCHK(hipMalloc((void **)dev, n * sizeof(float)));
+    m->owned.push_back(*dev);
+    BFCHK(hipMemcpy(*dev, host, n * sizeof(float), hipMemcpyHostToDevice));
+    return IDM_OK;
+}
+
+// tensor index helpers (order documented in include/isingdiff.h)
+enum { T_IN_W = 0, T_IN_B, T_D1_W, T_D1_B, T_D2_W, T_D2_B, T_BLK0 };
+enum { K_T_W = 0, K_T_B, K_G1_G, K_G1_B, K_C1_W, K_C1_B, K_G2_G, K_G2_B, K_C2_W, K_C2_B, K_S_W, K_S_B, K_PER_BLK };
+inline int tb(int blk, int k) { return T_BLK0 + blk * K_PER_BLK + k; }
+constexpr int T_OUT_W = T_BLK0 + NBLK * K_PER_BLK, T_OUT_B = T_OUT_W + 1;
+
+size_t tensor_elems(int idx)
+{
+    if (idx == T_IN_W || idx == T_IN_B) return 32;
+    if (idx == T_D1_W) return (size_t)EMB * TEMB;
+    if (idx == T_D2_W) return (size_t)TEMB * TEMB;
+    if (idx == T_D1_B || idx == T_D2_B) return TEMB;
+    if (idx == T_OUT_W) return 32;
+    if (idx == T_OUT_B) return 1;
+    const int blk = (idx - T_BLK0) / K_PER_BLK, k = (idx - T_BLK0) % K_PER_BLK;
+    const size_t ci = kCin[blk], w = kWidth[blk];
+    switch (k) {
+    case K_T_W: return TEMB * w;
+    case K_G1_G: case K_G1_B: return ci;
+    case K_C1_W: return 9 * ci * w;
+    case K_C2_W: return 9 * w * w;
+    case K_S_W: return ci * w;
+    default: return w;
+    }
+}
+
+int ensure(idm_bitflip *m, size_t bytes)
+{
+    if (bytes <= m->ws_bytes) return IDM_OK;
+    if (m->ws) (void)hipFree(m->ws);
+    m->ws = nullptr; m->ws_bytes = 0;
+    if (hipMalloc((void **)&m->ws, bytes) != hipSuccess) return idm_set_error(IDM_ERR_NOMEM, "bit-flip workspace allocation failed");
+    m->ws_bytes = bytes;
+    return IDM_OK;
+}
+
+// floats of workspace per sample (see forward_chunk)
+size_t ws_floats(int H, int W)
+{
+    const size_t hw = (size_t)H * W;
+    return hw * (32 + 32 + 16 + 8 + 96 + 96 + 32 + 8 + 16 + 32 + 1) + 2 * 192;
+}
+
+int time_vectors(idm_bitflip *m, const float *emb_host, int rows, hipStream_t s)
+{
+    if (rows > m->emb_cap) {
+        float *e = nullptr, *tv = nullptr;
+        BFCHK(hipMalloc((void **)&e, (size_t)rows * EMB * sizeof(float)));
+        BFCHK(hipMalloc((void **)&tv, (size_t)rows * TVEC * sizeof(float)));
+        m->owned.push_back(e); m->owned.push_back(tv);
+        m->emb_dev = e; m->tvec = tv; m->emb_cap = rows; m->tvec_cap = rows;
+    }
+    BFCHK(hipMemcpyAsync(m->emb_dev, emb_host, (size_t)rows * EMB * sizeof(float), hipMemcpyHostToDevice, s));
+    TimeW w;
+    w.d1_w = m->t[T_D1_W]; w.d1_b = m->t[T_D1_B]; w.d2_w = m->t[T_D2_W]; w.d2_b = m->t[T_D2_B];
+    for (int k = 0; k < NBLK; ++k) { w.t_w[k] = m->t[tb(k, K_T_W)]; w.t_b[k] = m->t[tb(k, K_T_B)]; }
+    hipLaunchKernelGGL(bf_time_kernel, dim3(rows), dim3(128), 0, s, (const float *)m->emb_dev, w, m->tvec);
+    BFCHK(hipGetLastError());
+    return IDM_OK;
+}
+
+void gn_silu(const float *x, int64_t B, int HW, int C, const float *gamma, const float *beta, float *ab, float *y, hipStream_t s)
+{
+    hipLaunchKernelGGL(bf_gn_stats_kernel, dim3((unsigned)((B * 8 + 3) / 4)), dim3(256), 0, s, x, B, HW, C, gamma, beta, ab);
+    const int64_t n = B * HW * C;
+    hipLaunchKernelGGL(bf_gn_apply_kernel, dim3(blocks(n)), dim3(256), 0, s, x, (const float *)ab, y, n, HW, C);
+}
+
+void conv3(const float *in, int64_t B, int H, int W, int Cin, const void *wpack, const float *bias, const float *tadd,
+           float *out, int Cout, hipStream_t s)
+{
+    ConvArgs a = {};
+    a.in0 = in; a.in1 = nullptr; a.C0 = Cin; a.C1 = 0; a.H = H; a.W = W; a.B = B; a.wpack = wpack; a.bias = bias;
+    a.scale = nullptr; a.shift = nullptr; a.tadd = tadd; a.out = out; a.Cout = Cout; a.mode = CONV_PLAIN; a.silu = 0;
+    a.out_f32 = 1;
+    launch_conv_f32(a, s);
+}
+
+// ResBlock (:168-193).  ta: >= B*H*W*max(Cin,width) floats, tbuf: >= B*H*W*width floats.
+void resblock(idm_bitflip *m, int i, const float *x, int64_t B, int H, int W, const float *tvec, float *out, float *ta,
+              float *tbuf, float *ab, hipStream_t s)
+{
+    const int Cin = kCin[i], Cw = kWidth[i], HW = H * W;
+    gn_silu(x, B, HW, Cin, m->t[tb(i, K_G1_G)], m->t[tb(i, K_G1_B)], ab, ta, s);
+    conv3(ta, B, H, W, Cin, m->c1_pack[i], m->t[tb(i, K_C1_B)], tvec, tbuf, Cw, s);
+    gn_silu(tbuf, B, HW, Cw, m->t[tb(i, K_G2_G)], m->t[tb(i, K_G2_B)], ab, ta, s);
+    conv3(ta, B, H, W, Cw, m->c2_pack[i], m->t[tb(i, K_C2_B)], nullptr, tbuf, Cw, s);
+    const int64_t npix = B * HW;
+    hipLaunchKernelGGL(bf_shortcut_kernel, dim3(blocks(npix * Cw)), dim3(256), 0, s, x, Cin, m->t[tb(i, K_S_W)],
+                       m->t[tb(i, K_S_B)], (const float *)tbuf, out, npix, Cw);
+}
+
+// Forward of Bc samples; tvec: this step's five time vectors (device); proba (Bc,H,W).
+int forward_chunk(idm_bitflip *m, const uint8_t *x, const float *tvec, float *proba, int64_t Bc, int H, int W,
+                  float *const *taps, int64_t tap_off, hipStream_t s)
+{
+    const size_t hw = (size_t)H * W;
+    float *p = (float *)m->ws;
+    auto take = [&](size_t per) { float *q = p; p += per * Bc; return q; };
+    float *x0 = take(hw * 32), *r0 = take(hw * 32), *r1 = take(hw * 16), *r2 = take(hw * 8), *cat = take(hw * 96),
+          *ta = take(hw * 96), *tbuf = take(hw * 32), *pl = take(hw * 8), *d3 = take(hw * 16), *d4 = take(hw * 32);
+    float *ab = p;  // (Bc, <=192, 2)
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+    const float *tv[NBLK];
+    int o = 0;
+    for (int i = 0; i < NBLK; ++i) { tv[i] = tvec + o; o += kWidth[i]; }
+    hipLaunchKernelGGL(bf_in_kernel, dim3(blocks(Bc * hw * 32)), dim3(256), 0, s, x, m->t[T_IN_W], m->t[T_IN_B], x0,
+                       (int64_t)(Bc * hw));
+    resblock(m, 0, x0, Bc, H, W, tv[0], r0, ta, tbuf, ab, s);
+    hipLaunchKernelGGL(bf_maxpool_kernel, dim3(blocks(Bc * hw * 8)), dim3(256), 0, s, (const float *)r0, pl, Bc, H, W, 32);
+    resblock(m, 1, pl, Bc, H2, W2, tv[1], r1, ta, tbuf, ab, s);
+    hipLaunchKernelGGL(bf_maxpool_kernel, dim3(blocks(Bc * hw * 4)), dim3(256), 0, s, (const float *)r1, pl, Bc, H2, W2, 64);
+    resblock(m, 2, pl, Bc, H4, W4, tv[2], r2, ta, tbuf, ab, s);
+    hipLaunchKernelGGL(bf_upcat_kernel, dim3(blocks(Bc * hw * 48)), dim3(256), 0, s, (const float *)r2, (const float *)r1,
+                       cat, Bc, H4, W4, 128, 64);
+    resblock(m, 3, cat, Bc, H2, W2, tv[3], d3, ta, tbuf, ab, s);
+    hipLaunchKernelGGL(bf_upcat_kernel, dim3(blocks(Bc * hw * 96)), dim3(256), 0, s, (const float *)d3, (const float *)r0,
+                       cat, Bc, H2, W2, 64, 32);
+    resblock(m, 4, cat, Bc, H, W, tv[4], d4, ta, tbuf, ab, s);
+    hipLaunchKernelGGL(bf_head_kernel, dim3(blocks(Bc * hw)), dim3(256), 0, s, (const float *)d4, m->t[T_OUT_W],
+                       m->t[T_OUT_B], proba, (int64_t)(Bc * hw));
+    if (taps) {
+        const float *src[NBLK] = {r0, r1, r2, d3, d4};
+        const size_t per[NBLK] = {hw * 32, hw * 16, hw * 8, hw * 16, hw * 32};
+        for (int i = 0; i < NBLK; ++i)
+            if (taps[i])
+                BFCHK(hipMemcpyAsync(taps[i] + (size_t)tap_off * per[i], src[i], per[i] * Bc * sizeof(float),
+                                     hipMemcpyDeviceToDevice, s));
+    }
+    BFCHK(hipGetLastError());
+    return IDM_OK;
+}
+
+int check_hw(int64_t B, int H, int W)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 3) || (W & 3))
+        return idm_set_error(IDM_ERR_INVALID, "bit-flip model: B > 0 and H, W multiples of 4 required (two 2x2 poolings)");
+    return IDM_OK;
+}
+
+int64_t pick_chunk(int64_t B, int H, int W, int64_t want)
+{
+    const size_t per = (ws_floats(H, W) + (size_t)H * W) * sizeof(float);
+    int64_t cap = (int64_t)((size_t)4 << 30) / (int64_t)per;
+    if (cap < 1) cap = 1;
+    int64_t c = want > 0 ? want : cap;
+    return std::min<int64_t>(std::min<int64_t>(c, cap), B);
+}
+
+}  // namespace
+
+extern "C" {
+
+int idm_bitflip_create(idm_bitflip **out, int device, const idm_bitflip_desc *d)
+{
+    if (!out || !d || d->n_tensors != IDM_BITFLIP_NTENSOR) return idm_set_error(IDM_ERR_INVALID, "bad bit-flip descriptor");
+    BFCHK(hipSetDevice(device));
+    idm_bitflip *m = new idm_bitflip();
+    m->device = device;
+    int rc = IDM_OK;
+    for (int i = 0; i < IDM_BITFLIP_NTENSOR && rc == IDM_OK; ++i) {
+        const int blk = (i - T_BLK0) / K_PER_BLK, k = (i - T_BLK0) % K_PER_BLK;
+        const bool in_blk = i >= T_BLK0 && i < T_OUT_W;
+        const bool optional = in_blk && (k == K_S_W || k == K_S_B) && kCin[blk] == kWidth[blk];
+        if (!d->tensors[i]) {
+            if (!optional) rc = idm_set_error(IDM_ERR_INVALID, "bit-flip descriptor: missing tensor");
+            continue;
+        }
+        float *dev = nullptr;
+        rc = bf_upload(m, d->tensors[i], tensor_elems(i), &dev);
+        m->t[i] = dev;
+        if (rc == IDM_OK && in_blk && (k == K_C1_W || k == K_C2_W)) {
+            const int ci = k == K_C1_W ? kCin[blk] : kWidth[blk];
+            std::vector<float> pk = idm_pack_weights_f32(d->tensors[i], ci, kWidth[blk]);
+            float *pd = nullptr;
+            rc = bf_upload(m, pk.data(), pk.size(), &pd);
+            (k == K_C1_W ? m->c1_pack : m->c2_pack)[blk] = pd;
+        }
+    }
+    if (rc != IDM_OK) {
+        idm_bitflip_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return IDM_OK;
+}
+
+int idm_bitflip_destroy(idm_bitflip *m)
+{
+    if (!m) return IDM_OK;
+    (void)hipSetDevice(m->device);
+    for (void *p : m->owned) (void)hipFree(p);
+    if (m->ws) (void)hipFree(m->ws);
+    delete m;
+    return IDM_OK;
+}
+
+int idm_bitflip_time(idm_bitflip *m, const float *emb_host, float *tvec_dev)
+{
+    if (!m || !emb_host || !tvec_dev) return idm_set_error(IDM_ERR_INVALID, "null argument");
+    BFCHK(hipSetDevice(m->device));
+    int rc = time_vectors(m, emb_host, 1, nullptr);
+    if (rc != IDM_OK) return rc;
+    BFCHK(hipMemcpyAsync(tvec_dev, m->tvec, TVEC * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+    BFCHK(hipStreamSynchronize(nullptr));
+    return IDM_OK;
+}
+
+int idm_bitflip_forward(idm_bitflip *m, const uint8_t *x_dev, const float *emb_host, float *proba_dev, int64_t B, int H,
+                        int W, float *const *taps_dev, void *stream)
+{
+    if (!m || !x_dev || !emb_host || !proba_dev) return idm_set_error(IDM_ERR_INVALID, "null argument");
+    int rc = check_hw(B, H, W);
+    if (rc != IDM_OK) return rc;
+    BFCHK(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = time_vectors(m, emb_host, 1, s)) != IDM_OK) return rc;
+    const int64_t chunk = pick_chunk(B, H, W, 0);
+    if ((rc = ensure(m, (size_t)chunk * ws_floats(H, W) * sizeof(float))) != IDM_OK) return rc;
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t bc = std::min<int64_t>(chunk, B - b0);
+        rc = forward_chunk(m, x_dev + (size_t)b0 * H * W, m->tvec, proba_dev + (size_t)b0 * H * W, bc, H, W, taps_dev, b0, s);
+        if (rc != IDM_OK) return rc;
+    }
+    return IDM_OK;
+}
+
+int idm_bitflip_sample(idm_bitflip *m, const idm_bitflip_cfg *cfg, uint8_t *x_dev, const float *uniforms_dev,
+                       uint8_t *traj_dev, int64_t B, int H, int W, void *stream)
+{
+    if (!m || !cfg || !x_dev || !cfg->emb_table_host || cfg->T <= 0) return idm_set_error(IDM_ERR_INVALID, "bad argument");
+    int rc = check_hw(B, H, W);
+    if (rc != IDM_OK) return rc;
+    BFCHK(hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int T = cfg->T;
+    if ((rc = time_vectors(m, cfg->emb_table_host, T, s)) != IDM_OK) return rc;
+    const int64_t chunk = pick_chunk(B, H, W, cfg->chunk);
+    const size_t hw = (size_t)H * W;
+    if ((rc = ensure(m, (size_t)chunk * (ws_floats(H, W) + hw) * sizeof(float))) != IDM_OK) return rc;
+    float *proba = (float *)m->ws + (size_t)chunk * ws_floats(H, W);
+    const size_t n = (size_t)B * hw;
+    if (traj_dev) BFCHK(hipMemcpyAsync(traj_dev, x_dev, n, hipMemcpyDeviceToDevice, s));
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t bc = std::min<int64_t>(chunk, B - b0);
+        uint8_t *xc = x_dev + (size_t)b0 * hw;
+        for (int t = T - 1; t >= 0; --t) {
+            rc = forward_chunk(m, xc, m->tvec + (size_t)t * TVEC, proba, bc, H, W, nullptr, 0, s);
+            if (rc != IDM_OK) return rc;
+            PhiloxArgs ph = {cfg->seed, cfg->first_global_index + b0, t};
+            const float *u = uniforms_dev ? uniforms_dev + (size_t)t * n + (size_t)b0 * hw : nullptr;
+            hipLaunchKernelGGL(bf_flip_kernel, dim3(blocks(bc * (int64_t)((hw + 3) / 4))), dim3(256), 0, s, xc,
+                               (const float *)proba, u, bc, (int)hw, ph);
+            if (traj_dev)
+                BFCHK(hipMemcpyAsync(traj_dev + (size_t)(T - t) * n + (size_t)b0 * hw, xc, (size_t)bc * hw,
+                                     hipMemcpyDeviceToDevice, s));
+        }
+    }
+    BFCHK(hipGetLastError());
+    return IDM_OK;
+}
+
+}  // extern "C"

@@ -4,6 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
+// Records the message idm_last_error() returns on this thread; returns `code`.
+int idm_set_error(int code, const char *msg);
+// Keras kernel (3,3,Cin,Cout) -> float A operands of v_mfma_f32_32x32x2_f32, [tap][c/8][mt][lane][4].
+std::vector<float> idm_pack_weights_f32(const float *w, int cin, int cout);
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;

@@ -7,6 +7,8 @@ models.  Public surface mirrors the reference script's callables:
     sample(model, n, L)                       the script's sampling + sign projection + observables
     ising_energy / ising_magnetization        b_pure_metoropolis_2d_ising helpers
     onsager_energy …                          onsager.py
+    bitflip.BitflipModel / bitflip.diffusion_backward
+                                              mnist_diffusion.py: model([X, t]) and its XOR sampler
 """
 from .keras_file import UNetSpec, load_unet_spec
 from .onsager import onsager_energy, onsager_heat_capacity, onsager_magnetization, theoretical_critical_kT

@@ -44,6 +44,18 @@ class ProfileEntry(C.Structure):
                 ("bytes", C.c_double)]
 
 
+BITFLIP_NTENSOR = 68
+
+
+class BitflipDesc(C.Structure):
+    _fields_ = [("n_tensors", C.c_int32), ("reserved", C.c_int32), ("tensors", C.c_void_p * BITFLIP_NTENSOR)]
+
+
+class BitflipCfg(C.Structure):
+    _fields_ = [("T", C.c_int32), ("reserved", C.c_int32), ("emb_table_host", C.c_void_p), ("seed", C.c_uint64),
+                ("first_global_index", C.c_int64), ("chunk", C.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/isingdiff.h declares
 SIGNATURES = {
     "idm_abi_version": (C.c_int, []),
@@ -65,6 +77,13 @@ SIGNATURES = {
     "idm_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "idm_profile_begin": (C.c_int, [C.c_void_p]),
     "idm_profile_end": (C.c_int, [C.c_void_p, C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),
+    "idm_bitflip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(BitflipDesc)]),
+    "idm_bitflip_destroy": (C.c_int, [C.c_void_p]),
+    "idm_bitflip_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "idm_bitflip_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                      C.POINTER(C.c_void_p), C.c_void_p]),
+    "idm_bitflip_sample": (C.c_int, [C.c_void_p, C.POINTER(BitflipCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_int, C.c_int, C.c_void_p]),
 }
 
 _lib = None

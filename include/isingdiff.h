@@ -166,6 +166,55 @@ typedef struct {
 int idm_profile_begin(idm_model *m);
 int idm_profile_end(idm_model *m, idm_profile_entry *entries, int cap, int *n);
 
+/* ---------------------------------------------------------------------------------------------
+ * MNIST bit-flip diffusion (mnist_diffusion/mnist_diffusion.py): residual UNet with
+ * GroupNormalization(8) and per-block time vectors (create_improved_diffusion_unet :162-240),
+ * sampler X ^= uniform < model([X, t/time_step]) (diffusion_backward :43-52).  Float32 parity
+ * mode (canonical arithmetic) only.
+ *
+ * Weights: host float32 arrays in Keras layouts (conv (kh,kw,Cin,Cout), dense (in,out)), in this
+ * order: in_w,in_b (Conv2D 1x1 :207); d1_w,d1_b,d2_w,d2_b (time MLP :202-203); for each of the
+ * five ResBlocks (widths 32,64,128,64,32; inputs 32,32,64,192,96): t_w,t_b (Dense :173),
+ * g1_g,g1_b (GroupNorm gamma,beta :177), c1_w,c1_b (:179), g2_g,g2_b (:183), c2_w,c2_b (:185),
+ * s_w,s_b (1x1 shortcut :190, NULL where input width == width); out_w,out_b (:236). */
+#define IDM_BITFLIP_NTENSOR 68
+
+typedef struct {
+    int32_t n_tensors;   /* IDM_BITFLIP_NTENSOR */
+    int32_t reserved;
+    const float *tensors[IDM_BITFLIP_NTENSOR];
+} idm_bitflip_desc;
+
+typedef struct {
+    int32_t T;                     /* time_step; t runs T-1 .. 0 */
+    int32_t reserved;
+    const float *emb_table_host;   /* (T, 32): SinusoidalPositionalEmbedding (:67-99) of float32(t)/float32(T) */
+    uint64_t seed;                 /* Philox key for the uniforms (used when uniforms_dev == NULL) */
+    int64_t first_global_index;    /* global index of sample 0 (uniforms do not depend on sharding) */
+    int64_t chunk;                 /* samples processed together; 0 = automatic */
+} idm_bitflip_cfg;
+
+typedef struct idm_bitflip idm_bitflip;
+
+int idm_bitflip_create(idm_bitflip **out, int device, const idm_bitflip_desc *desc);
+int idm_bitflip_destroy(idm_bitflip *m);
+
+/* The five per-block time vectors swish(Dense_i(temb)) (:173, :200-203) for one embedding row
+ * (32 host floats): 320 device floats.  Synchronises.  For tests. */
+int idm_bitflip_time(idm_bitflip *m, const float *emb_host, float *tvec_dev);
+
+/* flip_proba = model([X, t]) (:48).  x_dev (B,H,W) bytes 0/1; emb_host: the embedding row of t;
+ * proba_dev (B,H,W) float32; taps_dev NULL or 5 device buffers receiving the ResBlock outputs
+ * (B,h_i,w_i,width_i) (entries may be NULL).  H, W multiples of 4. */
+int idm_bitflip_forward(idm_bitflip *m, const uint8_t *x_dev, const float *emb_host, float *proba_dev,
+                        int64_t B, int H, int W, float *const *taps_dev, void *stream);
+
+/* diffusion_backward (:43-52).  x_dev (B,H,W) bytes: X_b on entry, final state on return;
+ * uniforms_dev NULL, or (T,B,H,W) float32 indexed by t (deterministic mode: flip = u[t] < p);
+ * traj_dev NULL, or (T+1,B,H,W) bytes in the reference's order (traj[0] = X_b, traj[k] = after k steps). */
+int idm_bitflip_sample(idm_bitflip *m, const idm_bitflip_cfg *cfg, uint8_t *x_dev, const float *uniforms_dev,
+                       uint8_t *traj_dev, int64_t B, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,8 +18,8 @@ _LIB = None
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libref_cpu.so")
-    src = os.path.join(_HERE, "ref_cpu.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, n) for n in ("ref_cpu.c", "ref_bitflip.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 
@@ -49,6 +49,15 @@ def lib():
         L.ref_cexp.argtypes = [C.c_float]
         L.ref_silu.restype = C.c_float
         L.ref_silu.argtypes = [C.c_float]
+        L.ref_bitflip_create.restype = C.c_void_p
+        L.ref_bitflip_create.argtypes = [pp]
+        L.ref_bitflip_destroy.argtypes = [C.c_void_p]
+        L.ref_rsqrt_canon.restype = C.c_float
+        L.ref_rsqrt_canon.argtypes = [C.c_float]
+        L.ref_bitflip_time.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_bitflip_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, pp]
+        L.ref_bitflip_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_int, C.c_int]
         _LIB = L
     return _LIB
 
@@ -172,3 +181,64 @@ def philox4x32(counter, key) -> np.ndarray:
 def beta_schedule(T: int = 1000) -> np.ndarray:
     """float32(linspace(1e-4, 0.02, T)) (b_diffusion_model_unet_2d_ising.py:168-172)."""
     return np.linspace(1e-4, 0.02, T).astype(np.float32)
+
+
+class RefBitflip:
+    """C-oracle MNIST bit-flip UNet (``ref_bitflip.c``) from a dict of Keras-layout tensors and the
+    tensor order of the C boundary (``names``; missing optional tensors are passed as NULL)."""
+
+    WIDTH = (32, 64, 128, 64, 32)
+
+    def __init__(self, weights: dict, names):
+        self._keep = []
+        arrs = []
+        for n in names:
+            if n in weights:
+                a = np.ascontiguousarray(weights[n], np.float32)
+                self._keep.append(a)
+                arrs.append(a)
+            else:
+                arrs.append(None)
+        self._h = lib().ref_bitflip_create(_ptr_array(arrs))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _LIB is not None:
+            _LIB.ref_bitflip_destroy(h)
+
+    def time_vectors(self, emb_row: np.ndarray) -> np.ndarray:
+        emb_row = np.ascontiguousarray(emb_row, np.float32)
+        out = np.empty(sum(self.WIDTH), np.float32)
+        lib().ref_bitflip_time(self._h, _ptr(emb_row), _ptr(out))
+        return out
+
+    def forward(self, x: np.ndarray, emb_row: np.ndarray, taps: bool = False):
+        """x (B,H,W) uint8 0/1 -> flip probabilities (B,H,W) float32 (and the five ResBlock outputs)."""
+        x = np.ascontiguousarray(x, np.uint8)
+        B, H, W = x.shape
+        tv = self.time_vectors(emb_row)
+        p = np.empty((B, H, W), np.float32)
+        if not taps:
+            lib().ref_bitflip_forward(self._h, _ptr(x), _ptr(tv), _ptr(p), B, H, W, None)
+            return p
+        shp = [(H, W, 32), (H // 2, W // 2, 64), (H // 4, W // 4, 128), (H // 2, W // 2, 64), (H, W, 32)]
+        outs = [np.empty((B,) + s, np.float32) for s in shp]
+        lib().ref_bitflip_forward(self._h, _ptr(x), _ptr(tv), _ptr(p), B, H, W, _ptr_array(outs))
+        return p, outs
+
+    def sample(self, x: np.ndarray, emb_table: np.ndarray, uniforms: np.ndarray, trajectory: bool = False):
+        """Reverse sampler with injected uniforms (T,B,H,W) indexed by t; returns the final state
+        (and the (T+1,B,H,W) trajectory in the reference's order)."""
+        x = np.array(x, np.uint8, order="C")
+        B, H, W = x.shape
+        emb_table = np.ascontiguousarray(emb_table, np.float32)
+        T = emb_table.shape[0]
+        u = np.ascontiguousarray(uniforms, np.float32)
+        assert u.shape == (T, B, H, W)
+        traj = np.empty((T + 1, B, H, W), np.uint8) if trajectory else None
+        lib().ref_bitflip_sample(self._h, _ptr(x), _ptr(emb_table), T, _ptr(u), _ptr(traj), B, H, W)
+        return (x, traj) if trajectory else x
+
+
+def rsqrt_canon(v: float) -> float:
+    return float(lib().ref_rsqrt_canon(np.float32(v)))

@@ -125,3 +125,50 @@ def ising_energy(spins: np.ndarray, J: float, h: float) -> np.ndarray:
 
 def ising_magnetization(spins: np.ndarray) -> np.ndarray:
     return np.mean(spins.astype(np.float64), (1, 2))
+
+
+class TorchBitflipUNet:
+    """Independent PyTorch-CPU restatement of ``create_improved_diffusion_unet``
+    (``mnist_diffusion/mnist_diffusion.py:162-240``) with library ops (``group_norm``, ``conv2d``,
+    ``max_pool2d``): cross-checks ``ref_bitflip.c``, whose arithmetic order is hand-fixed.
+    ``weights``: dict of Keras-layout tensors named as at the C boundary."""
+
+    CIN = (32, 32, 64, 192, 96)
+    WIDTH = (32, 64, 128, 64, 32)
+
+    def __init__(self, weights: dict, dtype=torch.float64):
+        self.dtype = dtype
+        self.w = {k: torch.from_numpy(np.asarray(v, np.float64)).to(dtype) for k, v in weights.items()}
+
+    def _conv(self, x, name_w, name_b, pad):
+        w = self.w[name_w].permute(3, 2, 0, 1).contiguous()   # (kh,kw,Cin,Cout) -> (Cout,Cin,kh,kw)
+        return F.conv2d(x, w, self.w[name_b], padding=pad)
+
+    def _res(self, i, x, temb):
+        ci, wd = self.CIN[i], self.WIDTH[i]
+        tm = F.silu(temb @ self.w[f"b{i}_t_w"] + self.w[f"b{i}_t_b"])
+        h = F.silu(F.group_norm(x, 8, self.w[f"b{i}_g1_g"], self.w[f"b{i}_g1_b"], eps=1e-3))
+        h = self._conv(h, f"b{i}_c1_w", f"b{i}_c1_b", 1) + tm[:, :, None, None]
+        h = F.silu(F.group_norm(h, 8, self.w[f"b{i}_g2_g"], self.w[f"b{i}_g2_b"], eps=1e-3))
+        h = self._conv(h, f"b{i}_c2_w", f"b{i}_c2_b", 1)
+        if ci != wd:
+            x = self._conv(x, f"b{i}_s_w", f"b{i}_s_b", 0)
+        return x + h
+
+    @torch.no_grad()
+    def __call__(self, x01: np.ndarray, emb_row: np.ndarray, taps: bool = False):
+        """x01 (B,H,W) 0/1; emb_row (32,) sinusoidal embedding of this step -> flip probabilities (B,H,W)."""
+        x = torch.from_numpy(np.asarray(x01, np.float64)).to(self.dtype)[:, None]          # NCHW
+        e = torch.from_numpy(np.asarray(emb_row, np.float64)).to(self.dtype)[None]
+        temb = F.silu(e @ self.w["d1_w"] + self.w["d1_b"])
+        temb = F.silu(temb @ self.w["d2_w"] + self.w["d2_b"])
+        x = self._conv(x, "in_w", "in_b", 0)
+        s1 = self._res(0, x, temb)
+        s2 = self._res(1, F.max_pool2d(s1, 2), temb)
+        mid = self._res(2, F.max_pool2d(s2, 2), temb)
+        d3 = self._res(3, torch.cat([F.interpolate(mid, scale_factor=2, mode="nearest"), s2], 1), temb)
+        d4 = self._res(4, torch.cat([F.interpolate(d3, scale_factor=2, mode="nearest"), s1], 1), temb)
+        p = torch.sigmoid(self._conv(d4, "out_w", "out_b", 0))[:, 0]
+        if taps:
+            return p.numpy(), [t.permute(0, 2, 3, 1).numpy() for t in (s1, s2, mid, d3, d4)]
+        return p.numpy()

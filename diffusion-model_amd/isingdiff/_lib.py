@@ -56,6 +56,15 @@ class BitflipCfg(C.Structure):
                 ("first_global_index", C.c_int64), ("chunk", C.c_int64)]
 
 
+MLP_MAXLAYERS = 8
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("reserved", C.c_int32), ("in_dim", C.c_int32 * MLP_MAXLAYERS),
+                ("out_dim", C.c_int32 * MLP_MAXLAYERS), ("act", C.c_int32 * MLP_MAXLAYERS),
+                ("w", C.c_void_p * MLP_MAXLAYERS), ("b", C.c_void_p * MLP_MAXLAYERS)]
+
+
 # name -> (restype, argtypes); every symbol include/isingdiff.h declares
 SIGNATURES = {
     "idm_abi_version": (C.c_int, []),
@@ -77,6 +86,11 @@ SIGNATURES = {
     "idm_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "idm_profile_begin": (C.c_int, [C.c_void_p]),
     "idm_profile_end": (C.c_int, [C.c_void_p, C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),
+    "idm_mlp_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(MlpDesc)]),
+    "idm_mlp_destroy": (C.c_int, [C.c_void_p]),
+    "idm_mlp_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "idm_mlp_sample": (C.c_int, [C.c_void_p, C.POINTER(SampleCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.c_void_p]),
     "idm_bitflip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(BitflipDesc)]),
     "idm_bitflip_destroy": (C.c_int, [C.c_void_p]),
     "idm_bitflip_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -215,6 +215,37 @@ int idm_bitflip_forward(idm_bitflip *m, const uint8_t *x_dev, const float *emb_h
 int idm_bitflip_sample(idm_bitflip *m, const idm_bitflip_cfg *cfg, uint8_t *x_dev, const float *uniforms_dev,
                        uint8_t *traj_dev, int64_t B, int H, int W, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dense spectral score model (b_diffusion_model_fft_2d_ising.py:105-114: Sequential of Dense
+ * layers on [x | t_norm], saved as models/b_diffusion_model_2d_ising.keras) and its sampler
+ * (:19-38).  Float32 parity mode (canonical arithmetic).  Layer widths up to 448. */
+#define IDM_MLP_MAXLAYERS 8
+
+typedef struct {
+    int32_t n_layers;
+    int32_t reserved;
+    int32_t in_dim[IDM_MLP_MAXLAYERS];    /* in_dim[0] = n + 1 (state plus the t_norm column) */
+    int32_t out_dim[IDM_MLP_MAXLAYERS];   /* out_dim[last] = n */
+    int32_t act[IDM_MLP_MAXLAYERS];       /* 0 = linear, 1 = tanh */
+    const float *w[IDM_MLP_MAXLAYERS];    /* host, Keras layout (in, out) */
+    const float *b[IDM_MLP_MAXLAYERS];
+} idm_mlp_desc;
+
+typedef struct idm_mlp idm_mlp;
+
+int idm_mlp_create(idm_mlp **out, int device, const idm_mlp_desc *desc);
+int idm_mlp_destroy(idm_mlp *m);
+
+/* score = score_model(concat([x, t_norm])) (:28-30).  x_dev, score_dev (B, n) float32. */
+int idm_mlp_forward(idm_mlp *m, const float *x_dev, float t_norm, float *score_dev, int64_t B, void *stream);
+
+/* diffusion_backward (:19-38): cfg as for idm_sample (precision must be IDM_FP32; chunk unused).
+ * x_dev (B, n): x_T on entry (or drawn here when cfg->init_state), final state on return;
+ * noise_dev NULL or (T, B, n) standard normals indexed by t; traj_dev NULL or (T+1, B, n) with
+ * traj[T] = x_T and traj[t] = state after step t (the reference's return layout). */
+int idm_mlp_sample(idm_mlp *m, const idm_sample_cfg *cfg, float *x_dev, const float *noise_dev, float *traj_dev,
+                   int64_t B, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -242,3 +242,40 @@ class RefBitflip:
 
 def rsqrt_canon(v: float) -> float:
     return float(lib().ref_rsqrt_canon(np.float32(v)))
+
+
+class RefDense:
+    """C-oracle dense score model (``ref_mlp.c``) from lists of Keras-layout kernels/biases."""
+
+    def __init__(self, kernels, biases, activations):
+        self.k = [np.ascontiguousarray(k, np.float32) for k in kernels]
+        self.b = [np.ascontiguousarray(b, np.float32) for b in biases]
+        self.nl = len(self.k)
+        self.n = self.k[-1].shape[1]
+        self.ind = (C.c_int * self.nl)(*[k.shape[0] for k in self.k])
+        self.outd = (C.c_int * self.nl)(*[k.shape[1] for k in self.k])
+        self.act = (C.c_int * self.nl)(*[int(a == "tanh") for a in activations])
+        L = lib()
+        pp = C.POINTER(C.c_void_p)
+        L.ref_mlp_forward.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, pp, pp, C.c_void_p, C.c_float,
+                                      C.c_void_p, C.c_int]
+        L.ref_mlp_sample.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, pp, pp, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_int]
+        L.ref_ctanh.restype = C.c_float
+        L.ref_ctanh.argtypes = [C.c_float]
+
+    def forward(self, x, t_norm):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty_like(x)
+        lib().ref_mlp_forward(self.nl, self.ind, self.outd, self.act, _ptr_array(self.k), _ptr_array(self.b), _ptr(x),
+                              np.float32(t_norm), _ptr(out), x.shape[0])
+        return out
+
+    def sample(self, x_T, betas, T, noise_z=None, trajectory=False):
+        x = np.array(x_T, np.float32, order="C")
+        betas = np.ascontiguousarray(betas, np.float32)
+        z = None if noise_z is None else np.ascontiguousarray(noise_z, np.float32)
+        traj = np.empty((T + 1,) + x.shape, np.float32) if trajectory else None
+        lib().ref_mlp_sample(self.nl, self.ind, self.outd, self.act, _ptr_array(self.k), _ptr_array(self.b), _ptr(x),
+                             _ptr(betas), T, _ptr(z), _ptr(traj), x.shape[0])
+        return (x, traj) if trajectory else x

@@ -96,6 +96,7 @@ struct idm_model {
     bool bn = false;
     int cin[IDM_NCONV], cout[IDM_NCONV];
     bool use_fused = true;                 // bf16: fused band kernels where they fit
+    int strip_below_rows = 8;              // fused bands shorter than this run as strip kernels instead
     void *w_first_pack = nullptr;          // layer 0 as one bf16 MFMA A fragment (C == 1)
     float *w_first = nullptr;              // (9, C, F) float32
     float *w_head = nullptr;               // (F, C) float32
@@ -135,8 +136,10 @@ struct Plan {
     int H, W, Hp, Wp;
     size_t es;  // activation element size
     size_t off_a0, off_s1, off_a2, off_s2, off_a4, off_a5, off_a6, off_a7, off_a8, off_a9, off_score, per_lattice;
-    bool fused;          // bf16 fused band kernels usable for this shape
+    bool fused;          // bf16 band kernels usable for this shape
     int R[5];            // band rows per fused kernel
+    bool strip[5];       // this pair of layers runs as single-convolution strip kernels instead
+    int sR[SK_COUNT], sWS[SK_COUNT];   // band rows / strip columns of the strip kernels
 };
 
 // Everything the last fused kernel needs to apply the reverse-diffusion update in place.
@@ -161,6 +164,23 @@ int pick_band_rows(int kind, int H, int W)
         int in = 0, mid = 0;
         fused_lds_bytes(kind, W, R, &in, &mid);
         if (in + mid <= limit && fused_band_fits(kind, W, R)) return R;
+    }
+    return 0;
+}
+
+// Band height for a single-convolution strip kernel (strip width = min(32, W)); 0 = not applicable.
+int pick_strip_rows(int kind, int H, int W, int *WS)
+{
+    const int ws = W < 32 ? W : 32;
+    *WS = ws;
+    if (W % ws != 0 || (ws & 3)) return 0;
+    const int cand[4] = {16, 8, 4, 2};
+    for (int i = 0; i < 4; ++i) {
+        const int R = cand[i];
+        if (R > H || H % R != 0) continue;
+        int in = 0, st = 0, cs = 0;
+        strip_lds_bytes(kind, R, ws, &in, &st, &cs);
+        if (in + st + cs <= 78 * 1024 && strip_fits(kind, R, ws)) return R;
     }
     return 0;
 }
@@ -191,9 +211,20 @@ Plan make_plan(const idm_model *m, int H, int W, int precision)
     p.fused = precision == IDM_BF16 && m->C == 1 && !m->bn && m->use_fused && m->w_first_pack != nullptr;
     if (p.fused) {
         const int hh[5] = {p.Hp, p.Hp / 2, p.Hp / 4, p.Hp / 2, p.Hp}, ww[5] = {p.Wp, p.Wp / 2, p.Wp / 4, p.Wp / 2, p.Wp};
+        // layers of each fused kernel as strip kernels: {conv1}, {conv2, conv3}, {conv4, conv5}, {conv6, conv7}, {conv8, conv9}
+        const int first[5] = {SK_CONV1, SK_CONV2, SK_CONV4, SK_CONV6, SK_CONV8}, count[5] = {1, 2, 2, 2, 2};
+        const bool quads = (p.W & 3) == 0 && p.H == p.Hp && p.W == p.Wp;
         for (int k = 0; k < 5; ++k) {
             p.R[k] = pick_band_rows(k, hh[k], ww[k]);
-            if (p.R[k] == 0) p.fused = false;
+            bool ok = quads && k != FK_A;   // conv0 has no strip kernel: fused_A runs at any band height that fits
+            for (int j = 0; j < count[k]; ++j) {
+                const int sk = first[k] + j;
+                p.sR[sk] = pick_strip_rows(sk, hh[k], ww[k], &p.sWS[sk]);
+                ok = ok && p.sR[sk] > 0;
+            }
+            // full-height fused bands where they fit; strips where the band would have to shrink
+            p.strip[k] = ok && (p.R[k] < m->strip_below_rows && p.R[k] < hh[k]);
+            if (p.R[k] == 0 && !p.strip[k]) p.fused = false;
         }
     }
     return p;
@@ -281,6 +312,27 @@ int forward_fused(idm_model *m, const Plan &p, const float *x, const float *tadd
         if (e != hipSuccess) return fail(IDM_ERR_HIP, std::string("launch ") + name + ": " + hipGetErrorString(e));
         return IDM_OK;
     };
+    // one layer as a strip kernel: sk = SK_CONV<l>
+    auto strip = [&](int sk, int l, const char *name, const void *in_a, const void *in_b, void *out, void *out_pool,
+                     int H, int W, double flop, double bytes, bool head) -> int {
+        StripArgs a = {};
+        a.H = H; a.W = W; a.R = p.sR[sk]; a.WS = p.sWS[sk]; a.nbands = H / a.R; a.nstrips = W / a.WS;
+        a.Hx = p.H; a.Wx = p.W; a.B = Bc;
+        a.in_a = in_a; a.in_b = in_b; a.w = m->wpack_bf16[l]; a.bias = m->bias[l]; a.tadd = l == 4 ? tadd : nullptr;
+        a.out = out; a.out_pool = out_pool;
+        if (head) {
+            a.w_head = m->w_head; a.b_head = m->bias[10]; a.score_out = score;
+            a.do_update = ctx.do_update ? 1 : 0;
+            a.x = ctx.x; a.noise = ctx.noise; a.add_noise = ctx.add_noise ? 1 : 0; a.ph = ctx.ph; a.beta = ctx.beta;
+            step_constants(ctx.beta, &a.c1, &a.sd);
+        }
+        strip_lds_bytes(sk, a.R, a.WS, &a.lds_in_bytes, &a.lds_stage_bytes, &a.lds_const_bytes);
+        hipError_t e = hipSuccess;
+        timed(m, name, flop, bytes, s, [&] { e = launch_strip(sk, a, s); });
+        if (e != hipSuccess) return fail(IDM_ERR_HIP, std::string("launch ") + name + ": " + hipGetErrorString(e));
+        return IDM_OK;
+    };
+    void *c2 = buf(p.off_a6), *c4 = buf(p.off_a4), *c6 = buf(p.off_a6), *c8 = buf(p.off_a8);
     auto layer = [&](FusedArgs &a, int l1, int l2) {
         a.w1 = l1 == 0 ? m->w_first_pack : m->wpack_bf16[l1];
         a.b1 = m->bias[l1];
@@ -294,14 +346,24 @@ int forward_fused(idm_model *m, const Plan &p, const float *x, const float *tadd
         rc = run(FK_A, "fused_A(conv0,1)", a, Hp, Wp, 2.0 * 9 * (F + F * F) * n1, (double)Bc * p.H * p.W * 4 + n1 * F * 2 + n2 * F * 2);
         if (rc != IDM_OK) return rc;
     }
-    {   // pooled -> conv2 -> conv3 -> skip2 (+ pooled)
+    if (p.strip[FK_M1]) {
+        rc = strip(SK_CONV2, 2, "strip_conv2", p1, nullptr, c2, nullptr, Hp / 2, Wp / 2, 2.0 * 9 * F * 2 * F * n2, n2 * F * 2 + n2 * 2 * F * 2, false);
+        if (rc == IDM_OK)
+            rc = strip(SK_CONV3, 3, "strip_conv3", c2, nullptr, s2, p2, Hp / 2, Wp / 2, 2.0 * 9 * 4 * F * F * n2, n2 * 2 * F * 4 + n4 * 2 * F * 2, false);
+        if (rc != IDM_OK) return rc;
+    } else {   // pooled -> conv2 -> conv3 -> skip2 (+ pooled)
         FusedArgs a = {};
         layer(a, 2, 3);
         a.in_a = p1; a.out = s2; a.out_pool = p2;
         rc = run(FK_M1, "fused_M1(conv2,3)", a, Hp / 2, Wp / 2, 2.0 * 9 * (F * 2 * F + 4 * F * F) * n2, n2 * F * 2 + n2 * 2 * F * 2 + n4 * 2 * F * 2);
         if (rc != IDM_OK) return rc;
     }
-    {   // pooled -> conv4 (+time) -> conv5
+    if (p.strip[FK_M2]) {
+        rc = strip(SK_CONV4, 4, "strip_conv4", p2, nullptr, c4, nullptr, Hp / 4, Wp / 4, 2.0 * 9 * 8 * F * F * n4, n4 * 2 * F * 2 + n4 * 4 * F * 2, false);
+        if (rc == IDM_OK)
+            rc = strip(SK_CONV5, 5, "strip_conv5", c4, nullptr, a5, nullptr, Hp / 4, Wp / 4, 2.0 * 9 * 16 * F * F * n4, n4 * 4 * F * 4, false);
+        if (rc != IDM_OK) return rc;
+    } else {   // pooled -> conv4 (+time) -> conv5
         FusedArgs a = {};
         layer(a, 4, 5);
         a.tadd1 = tadd;
@@ -309,14 +371,25 @@ int forward_fused(idm_model *m, const Plan &p, const float *x, const float *tadd
         rc = run(FK_M2, "fused_M2(conv4,5)", a, Hp / 4, Wp / 4, 2.0 * 9 * (8 * F * F + 16 * F * F) * n4, n4 * 2 * F * 2 + n4 * 4 * F * 2);
         if (rc != IDM_OK) return rc;
     }
-    {   // [up(conv5), skip2] -> conv6 -> conv7
+    if (p.strip[FK_M3]) {
+        rc = strip(SK_CONV6, 6, "strip_conv6", a5, s2, c6, nullptr, Hp / 2, Wp / 2, 2.0 * 9 * 12 * F * F * n2, n4 * 4 * F * 2 + n2 * 2 * F * 4, false);
+        if (rc == IDM_OK)
+            rc = strip(SK_CONV7, 7, "strip_conv7", c6, nullptr, a7, nullptr, Hp / 2, Wp / 2, 2.0 * 9 * 4 * F * F * n2, n2 * 2 * F * 4, false);
+        if (rc != IDM_OK) return rc;
+    } else {   // [up(conv5), skip2] -> conv6 -> conv7
         FusedArgs a = {};
         layer(a, 6, 7);
         a.in_a = a5; a.in_b = s2; a.out = a7;
         rc = run(FK_M3, "fused_M3(conv6,7)", a, Hp / 2, Wp / 2, 2.0 * 9 * (12 * F * F + 4 * F * F) * n2, n4 * 4 * F * 2 + n2 * 2 * F * 2 + n2 * 2 * F * 2);
         if (rc != IDM_OK) return rc;
     }
-    {   // [up(conv7), skip1] -> conv8 -> conv9 -> head -> (update)
+    if (p.strip[FK_B]) {
+        rc = strip(SK_CONV8, 8, "strip_conv8", a7, s1, c8, nullptr, Hp, Wp, 2.0 * 9 * 3 * F * F * n1, n2 * 2 * F * 2 + n1 * F * 4, false);
+        if (rc == IDM_OK)
+            rc = strip(SK_CONV9, 9, "strip_conv9(head,step)", c8, nullptr, nullptr, nullptr, Hp, Wp, 2.0 * 9 * F * F * n1 + 2.0 * F * n1,
+                       n1 * F * 2 + (double)Bc * p.H * p.W * 8, true);
+        if (rc != IDM_OK) return rc;
+    } else {   // [up(conv7), skip1] -> conv8 -> conv9 -> head -> (update)
         FusedArgs a = {};
         layer(a, 8, 9);
         a.in_a = a7; a.in_b = s1;
@@ -669,6 +742,7 @@ int idm_set_option(idm_model *m, const char *name, int value)
 {
     if (!m || !name) return fail(IDM_ERR_INVALID, "null argument");
     if (!strcmp(name, "fused")) { m->use_fused = value != 0; return IDM_OK; }
+    if (!strcmp(name, "strip_below_rows")) { m->strip_below_rows = value; return IDM_OK; }
     return fail(IDM_ERR_INVALID, std::string("unknown option ") + name);
 }
 

@@ -19,282 +19,11 @@
 // one zero column each side and a position stride of 2*C + 16 bytes: the 16-byte pad makes the
 // 16-lane groups of ds_read_b128 hit distinct banks without any address swizzle, so every operand
 // address is base + compile-time/scalar offset.
-#include "idm_internal.h"
-#include "idm_device.h"
+#include "idm_conv_stage.h"
 
 #include <algorithm>
-#include <type_traits>
 
 namespace {
-
-constexpr int WG = 256;
-
-enum { M1_PLAIN = 0, M1_UPCAT = 1, M1_FIRST = 2 };
-enum { E2_STORE = 0, E2_STORE_POOL = 1, E2_HEAD = 2 };
-
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-
-// silu of four values, written on float pairs so that everything but the two transcendentals
-// (v_exp_f32, v_rcp_f32: quarter rate) goes through the packed float32 ALU.
-DEVI f32x4 silu4(f32x4 z)
-{
-    const f32x2 nl = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.0f, 1.0f};
-    f32x2 z0 = {z[0], z[1]}, z1 = {z[2], z[3]};
-    f32x2 t0 = z0 * nl, t1 = z1 * nl;
-    f32x2 e0 = {__builtin_amdgcn_exp2f(t0[0]), __builtin_amdgcn_exp2f(t0[1])};
-    f32x2 e1 = {__builtin_amdgcn_exp2f(t1[0]), __builtin_amdgcn_exp2f(t1[1])};
-    e0 = e0 + one;
-    e1 = e1 + one;
-    f32x2 r0 = {__builtin_amdgcn_rcpf(e0[0]), __builtin_amdgcn_rcpf(e0[1])};
-    f32x2 r1 = {__builtin_amdgcn_rcpf(e1[0]), __builtin_amdgcn_rcpf(e1[1])};
-    z0 = z0 * r0;
-    z1 = z1 * r1;
-    return f32x4{z0[0], z0[1], z1[0], z1[1]};
-}
-
-DEVI bf16x4 pack4(float a, float b, float c, float d)
-{
-    bf16x4 o = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
-    return o;
-}
-
-template <int I, int N, class F>
-DEVI void static_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-// Buffer addressing: one scalar resource per tensor, a 32-bit per-lane byte offset and a scalar
-// constant per access (no 64-bit per-lane address arithmetic); reads beyond `bytes` return zero.
-DEVI __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
-}
-
-DEVI bf16x8 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
-{
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return __builtin_bit_cast(bf16x8, v);
-}
-
-// Per-lane geometry of the 32-pixel MFMA tiles of a map of width W, fixed for a kernel launch.
-// W <= 32: a tile is TR = 32 / W row slots of W pixels; lane li sits in slot li / W, column li % W,
-// and slot s of tile j is row j + s * Rh of the stage's output region (Rh = ceil(rows / TR)), so
-// that vertically adjacent tiles j, j+1, ... touch input rows that differ by exactly one.
-// W > 32: a tile is 32 consecutive columns of one row (ncb column blocks).
-struct LaneGeo {
-    int W, ncb, TR, slot, col;
-    bool ok;
-};
-
-DEVI LaneGeo make_geo(int W, int li)
-{
-    LaneGeo g;
-    g.W = W;
-    g.ncb = (W + 31) >> 5;
-    if (g.ncb == 1) {
-        g.TR = 32 / W;
-        g.slot = li / W;
-        g.col = li - g.slot * W;
-        g.ok = g.slot < g.TR;
-        if (!g.ok) g.slot = 0;
-    } else {
-        g.TR = 1;
-        g.slot = 0;
-        g.col = li;
-        g.ok = true;
-    }
-    return g;
-}
-
-// One 3x3 convolution stage over `nrows` output rows of an LDS-resident input tile.
-//
-// Work is cut into (cout slice, column block, row j) items and split evenly over the four
-// wavefronts; a wavefront processes up to NT vertically adjacent tiles at once.  Because tile n's
-// operand for tap row ky is input row j + n + ky, the NT + 2 activation fragments of one
-// (kx, channel group) "superstep" feed all 3 * NT MFMAs of that superstep: LDS traffic drops from
-// one 1 KB read per MFMA to (NT + 2) / (3 * NT * MS).  Supersteps are fully unrolled (static
-// register indices); activation fragments are read one superstep ahead, weights WD supersteps
-// ahead (L2 latency) into a register ring.  begin() fixes the partition and issues the first WD
-// weight fetches, so the caller can place it ahead of a barrier or a long-latency phase; run()
-// does the rest.
-//   PLAIN part: operand at  tile + ((row + ky)*(W+2) + col + kx)*S + 32*cg
-//   UP part:    the same on the half-resolution tile at row (row+ky)>>1, column (col+kx+1)>>1
-// Epilogue constants: c0 (bias) and, when HAS_C1, a second per-cout array c1 live in LDS as float32;
-// the 16 values a lane needs per cout tile are read during the last superstep and handed to epi().
-template <int CA, int CB, bool UP, int COUT, int NT, int MS, int WD, bool HAS_C1>
-struct ConvStage {
-    static constexpr int MTOT = COUT / 32, NSL = MTOT / MS;
-    static constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16;
-    static constexpr int NCG_A = CA / 16, NCG_B = CB / 16, NCG = NCG_A + NCG_B;
-    static constexpr int NS = 3 * NCG;
-    static constexpr int NPRE = WD < NS ? WD : NS;       // supersteps of weights fetched by begin()
-    static constexpr int WR = WD < NS ? WD + 1 : NS;     // ring slots
-    static constexpr bool FULL = WD >= NS;               // every weight of the stage is fetched by begin()
-
-    const char *lds_a, *lds_b;
-    const float *c0, *c1;
-    __amdgpu_buffer_rsrc_t wrsrc;   // weights: every fetch is buffer(base) + scalar constant + one 32-bit lane offset
-    unsigned wlane, woff;
-    LaneGeo g;
-    int h, r0, nrows, Rh, f, f1;
-    bf16x8 wreg[WR][3][MS];
-
-    DEVI void set_slice(int sl)
-    {
-        // The slice offset is made opaque to the optimiser: otherwise the weight loads are
-        // invariant across work items and get hoisted into (far too many) registers.  Laundering
-        // the offset, not the pointer, keeps the loads global_load: a laundered pointer degrades
-        // to flat_load, which also counts on lgkmcnt and turns every LDS wait into a wait for
-        // the weight prefetch.
-        unsigned o = (wlane + (unsigned)(sl * MS * 64)) * 16u;  // byte offset
-        asm volatile("" : "+v"(o));
-        woff = o;
-    }
-
-    template <int S>
-    DEVI void issue_w()
-    {
-        constexpr int kx = S / NCG, cg = S % NCG;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int m = 0; m < MS; ++m) wreg[S % WR][ky][m] = buf_load16(wrsrc, woff, (((ky * 3 + kx) * NCG + cg) * MTOT + m) * 1024);
-    }
-
-    DEVI void prologue()
-    {
-        static_for<0, NPRE>([&](auto S) { issue_w<decltype(S)::value>(); });
-    }
-
-    DEVI void begin(const char *la, const char *lb, const float *c0_, const float *c1_, const LaneGeo &geo, int r0_,
-                    int nrows_, const bf16x8 *w, int wave, int lane)
-    {
-        lds_a = la; lds_b = lb; c0 = c0_; c1 = c1_; g = geo; h = lane >> 5; r0 = r0_; nrows = nrows_;
-        wrsrc = make_rsrc(w, 9u * (CA + CB) * COUT * 2u);
-        wlane = (unsigned)lane;
-        Rh = (nrows + g.TR - 1) / g.TR;
-        const int tot = NSL * g.ncb * Rh;
-        f = (wave * tot) >> 2;
-        f1 = ((wave + 1) * tot) >> 2;
-        if (f < f1) {
-            set_slice((f / Rh) % NSL);
-            prologue();
-        }
-    }
-
-    template <int N, class Epi>
-    DEVI void piece(int j, int sl, int cb, Epi &&epi)
-    {
-        const int W = g.W, Wp2 = W + 2, Wh2 = (W >> 1) + 2;
-        const int cc = cb * 32 + g.col;
-        const int ca = min(cc, W - 1);
-        const int rbase = r0 + j + g.slot * Rh, rmax = r0 + nrows + 1;
-        int a_pl[N + 2], a_up[N + 2], a_b[N + 2], c_up[3];
-#pragma unroll
-        for (int i = 0; i < N + 2; ++i) {
-            const int r = min(rbase + i, rmax);
-            if constexpr (UP) a_up[i] = (r >> 1) * (Wh2 * SA);
-            else a_pl[i] = (r * Wp2 + ca) * SA + h * 16;
-            a_b[i] = (r * Wp2 + ca) * SB + h * 16;
-        }
-        if constexpr (UP) {
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) c_up[kx] = ((ca + kx + 1) >> 1) * SA + h * 16;
-        }
-        (void)a_pl; (void)a_up; (void)a_b; (void)c_up;
-
-        f32x16 acc[MS][N];
-#pragma unroll
-        for (int m = 0; m < MS; ++m)
-#pragma unroll
-            for (int n = 0; n < N; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-
-        bf16x8 fr[2][N + 2];
-        auto read_f = [&](auto S) {
-            constexpr int st = decltype(S)::value;
-            constexpr int kx = st / NCG, cg = st % NCG;
-#pragma unroll
-            for (int i = 0; i < N + 2; ++i) {
-                if constexpr (cg < NCG_A) {
-                    int addr;
-                    if constexpr (UP) addr = a_up[i] + c_up[kx];
-                    else addr = a_pl[i] + kx * SA;
-                    fr[st & 1][i] = *(const bf16x8 *)(lds_a + addr + cg * 32);
-                } else {
-                    fr[st & 1][i] = *(const bf16x8 *)(lds_b + a_b[i] + kx * SB + (cg - NCG_A) * 32);
-                }
-            }
-        };
-        f32x4 k0[MS][4], k1[MS][4];
-        if constexpr (!HAS_C1) {
-#pragma unroll
-            for (int m = 0; m < MS; ++m)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) k1[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        read_f(std::integral_constant<int, 0>{});
-        static_for<0, NS>([&](auto S) {
-            constexpr int st = decltype(S)::value;
-            // pin the software pipeline: without this the scheduler hoists every load of the
-            // unrolled loop to the top and spills
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (st + NPRE < NS) issue_w<st + NPRE>();
-            if constexpr (st + 1 < NS) read_f(std::integral_constant<int, st + 1>{});
-            if constexpr (st == NS - 1) {
-#pragma unroll
-                for (int m = 0; m < MS; ++m)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int co = (sl * MS + m) * 32 + 8 * q + 4 * h;
-                        k0[m][q] = *(const f32x4 *)(c0 + co);
-                        if constexpr (HAS_C1) k1[m][q] = *(const f32x4 *)(c1 + co);
-                    }
-            }
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int m = 0; m < MS; ++m)
-#pragma unroll
-                    for (int n = 0; n < N; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[st % WR][ky][m], fr[st & 1][n + ky],
-                                                                            acc[m][n], 0, 0, 0);
-        });
-#pragma unroll
-        for (int m = 0; m < MS; ++m)
-#pragma unroll
-            for (int n = 0; n < N; ++n)
-                epi(acc[m][n], k0[m], k1[m], sl * MS + m, rbase + n, cc, g.ok && cc < W && j + n + g.slot * Rh < nrows);
-    }
-
-    template <class Epi>
-    DEVI void run(Epi &&epi)
-    {
-        bool fetched = true;
-#pragma unroll 1
-        while (f < f1) {
-            const int u = f / Rh, j = f - u * Rh;
-            const int len = min(f1 - f, Rh - j);
-            const int np = (len + NT - 1) / NT, cnt = (len + np - 1) / np;
-            const int sl = u % NSL, cb = u / NSL;
-            if (!fetched) {
-                set_slice(sl);
-                prologue();
-            }
-            fetched = false;
-            static_for<1, NT + 1>([&](auto N) {
-                if (cnt == decltype(N)::value) piece<decltype(N)::value>(j, sl, cb, epi);
-            });
-            f += cnt;
-        }
-    }
-};
 
 // First layer (Cin = 1): K = 9 taps in one MFMA step; x = hi + lo in bf16, two MFMAs per tile.
 // xs: float32 tile [(rows)][W+2].  wfirst: one A fragment (lane l: cout l&31, k = 8*(l>>5)+j -> tap k).
@@ -781,7 +510,7 @@ namespace {
 // for the next band's input tiles.
 struct KindInfo { int mode1, ca, cb, c1, c2, epi2, npa, npb; };
 constexpr KindInfo kKinds[5] = {
-    {M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, 2, 0},    // FK_A : x -> conv0 -> conv1 -> skip1, pooled
+    {M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, 3, 0},    // FK_A : x -> conv0 -> conv1 -> skip1, pooled
     {M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, 5, 0},   // FK_M1: pooled -> conv2 -> conv3 -> skip2, pooled
     {M1_PLAIN, 64, 0, 128, 128, E2_STORE, 3, 0},      // FK_M2: pooled -> conv4 (+time) -> conv5
     {M1_UPCAT, 128, 64, 64, 64, E2_STORE, 3, 6},      // FK_M3: [up(conv5), skip2] -> conv6 -> conv7
@@ -850,7 +579,7 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
 
 // Tunables per kernel: NT1, MS1, WD1, NT2, MS2, WD2, NPA, NPB, OCC (overridable at build time for tuning runs).
 #ifndef IDM_CFG_A
-#define IDM_CFG_A 1, 1, 3, 2, 1, 6, 2, 0, 3
+#define IDM_CFG_A 1, 1, 3, 2, 1, 6, 3, 0, 3
 #endif
 #ifndef IDM_CFG_M1
 #define IDM_CFG_M1 3, 1, 3, 2, 1, 3, 5, 0, 2

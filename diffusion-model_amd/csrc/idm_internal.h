@@ -105,3 +105,32 @@ struct FusedArgs {
 void fused_lds_bytes(int kind, int W, int R, int *in_bytes, int *mid_bytes);
 bool fused_band_fits(int kind, int W, int R);
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s);
+
+// ---- single-convolution band/strip kernels (idm_strip.hip) ----
+enum StripKindId { SK_CONV1 = 0, SK_CONV2, SK_CONV3, SK_CONV4, SK_CONV5, SK_CONV6, SK_CONV7, SK_CONV8, SK_CONV9, SK_COUNT };
+
+struct StripArgs {
+    int H, W;          // map size of this layer's output (= its full-resolution input)
+    int R, WS;         // band rows (even) and strip columns (W % WS == 0, WS % 4 == 0)
+    int nbands, nstrips;
+    int Hx, Wx;        // HEAD: size of the unpadded state x
+    const void *in_a;  // plain: (B,H,W,CA); UP: (B,H/2,W/2,CA)
+    const void *in_b;  // UP: (B,H,W,CB)
+    const void *w;
+    const float *bias, *tadd;
+    void *out;         // (B,H,W,COUT) bf16
+    void *out_pool;    // POOL: (B,H/2,W/2,COUT) bf16
+    const float *w_head, *b_head;
+    float *x;
+    float *score_out;
+    const float *noise;
+    float c1, beta, sd;
+    int add_noise, do_update;
+    PhiloxArgs ph;
+    int lds_in_bytes, lds_stage_bytes, lds_const_bytes;
+    int64_t B;
+};
+
+void strip_lds_bytes(int kind, int R, int WS, int *in_bytes, int *stage_bytes, int *const_bytes);
+bool strip_fits(int kind, int R, int WS);
+hipError_t launch_strip(int kind, const StripArgs &a, hipStream_t s);

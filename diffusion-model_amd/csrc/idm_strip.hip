@@ -1,0 +1,357 @@
+// Single-convolution band/strip kernels (bf16 MFMA, float32 accumulate) for maps too large for the
+// fused two-convolution bands: one workgroup owns R rows x WS columns of one lattice's output,
+// stages the (R+2) x (WS+2) input window (zero outside the map) in LDS and runs one sliding-window
+// convolution stage on it.  No halo is recomputed (only re-read), every MFMA lane is a real
+// pixel, and the LDS footprint does not grow with the lattice size.  The UNet's data movement is
+// folded in exactly as in the fused kernels: UP reads Concatenate([UpSampling2D(a), skip]) by an
+// index shift on the half-resolution window, POOL also writes the 2x2 average, HEAD applies the
+// 1x1 head conv and the reverse-diffusion update (Philox noise drawn in-kernel).
+#include "idm_conv_stage.h"
+
+#include <algorithm>
+
+namespace {
+
+enum { SE_STORE = 0, SE_STORE_POOL = 1, SE_HEAD = 2 };
+
+// Register-held payload of one LDS input window: NP 16-byte items per thread (item i = tid + k*WG:
+// row i / (ncols*C/8), then column, then 8-channel group).  load() reads rows [g0, g0+nrows) x
+// columns [c0, c0+ncols) of a (Hmap, Wmap, C) bf16 map, zeros outside it (the buffer range check
+// returns zero for the out-of-range offset given to such items); store() writes the window.
+template <int C, int NP>
+struct WinRegs {
+    static constexpr int S = C * 2 + 16, CH = C / 8;
+    bf16x8 v[NP];
+
+    DEVI void load(const __bf16 *__restrict__ src, int Hmap, int Wmap, int g0, int nrows, int c0, int ncols, int tid)
+    {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, (unsigned)(Hmap * Wmap * C * 2));
+        const int ipr = ncols * CH;
+        int row = tid / ipr, rem = tid - row * ipr;
+        const int drow = WG / ipr, drem = WG - drow * ipr;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int col = rem / CH, ch = rem - col * CH;
+            const int g = g0 + row, c = c0 + col;
+            const bool ok = row < nrows && g >= 0 && g < Hmap && c >= 0 && c < Wmap;
+            v[k] = buf_load16(rs, ok ? (unsigned)(((g * Wmap + c) * CH + ch) * 16) : 0x80000000u, 0);
+            rem += drem;
+            row += drow;
+            if (rem >= ipr) { rem -= ipr; ++row; }
+        }
+    }
+
+    DEVI void store(char *tile, int nrows, int ncols, int tid) const
+    {
+        const int ipr = ncols * CH;
+        int row = tid / ipr, rem = tid - row * ipr;
+        const int drow = WG / ipr, drem = WG - drow * ipr;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int col = rem / CH, ch = rem - col * CH;
+            if (row < nrows) *(bf16x8 *)(tile + (row * ncols + col) * S + ch * 16) = v[k];
+            rem += drem;
+            row += drow;
+            if (rem >= ipr) { rem -= ipr; ++row; }
+        }
+    }
+};
+
+}  // namespace
+
+// Persistent: each workgroup walks work items wg = blockIdx.x, blockIdx.x + gridDim.x, ...;
+// item -> (lattice, band, strip) with the strip index fastest, so neighbouring workgroups share
+// their halo columns in L2.  Ordering of vector-memory traffic as in the fused kernels: the next
+// item's first weights are requested before its input, and both before the copy-out.
+template <int CA, int CB, bool UP, int COUT, int EPI, bool TADD, int NT, int MS, int WD, int NPA, int NPB, int OCC>
+__global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5;
+    const int W = a.W, H = a.H, R = a.R, WS = a.WS;
+    constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16, SO = COUT * 2 + 16;
+    (void)SB; (void)SO;
+    const int64_t per_lat = (int64_t)a.nbands * a.nstrips, total = a.B * per_lat;
+
+    // LDS map: [window a | window b | output staging | epilogue constants]
+    char *tile_a = smem;
+    char *tile_b = UP ? smem + ((((R >> 1) + 2) * ((WS >> 1) + 2) * SA + 15) & ~15) : nullptr;
+    char *stage = smem + a.lds_in_bytes;
+    constexpr int NCONST = 2 * COUT + 4;
+    float *cst = (float *)(smem + a.lds_in_bytes + a.lds_stage_bytes);
+    const float *c_b = cst, *c_2 = cst + COUT, *c_bh = cst + 2 * COUT;
+    (void)c_bh; (void)NCONST;
+    for (int i = tid; i < COUT; i += WG) {
+        cst[i] = a.bias[i];
+        cst[COUT + i] = EPI == SE_HEAD ? a.w_head[i] : (TADD ? a.tadd[i] : 0.0f);
+    }
+    if (tid == 0) cst[2 * COUT] = EPI == SE_HEAD ? a.b_head[0] : 0.0f;
+
+    const LaneGeo geo = make_geo(WS, lane & 31);
+    using Conv = ConvStage<CA, CB, UP, COUT, NT, MS, WD, TADD || EPI == SE_HEAD>;
+    Conv cs;
+
+    WinRegs<CA, NPA> ra;
+    WinRegs<UP ? CB : 8, UP ? NPB : 1> rb;
+    (void)rb;
+
+    auto item = [&](int64_t wg, int64_t &b, int &y0, int &x0) {
+        b = wg / per_lat;
+        const int r = (int)(wg - b * per_lat);
+        const int band = r / a.nstrips;
+        y0 = band * R;
+        x0 = (r - band * a.nstrips) * WS;
+    };
+    // (the thread index is made opaque per call so that the per-item index arithmetic of the window
+    // copies is recomputed per work item instead of being held in registers across the convolution)
+    auto pf_load = [&](int64_t wg) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        int64_t b; int y0, x0;
+        item(wg, b, y0, x0);
+        if constexpr (!UP) {
+            ra.load((const __bf16 *)a.in_a + (size_t)b * H * W * CA, H, W, y0 - 1, R + 2, x0 - 1, WS + 2, tid);
+        } else {
+            const int Hh = H >> 1, Wh = W >> 1;
+            ra.load((const __bf16 *)a.in_a + (size_t)b * Hh * Wh * CA, Hh, Wh, (y0 >> 1) - 1, (R >> 1) + 2, (x0 >> 1) - 1,
+                    (WS >> 1) + 2, tid);
+            rb.load((const __bf16 *)a.in_b + (size_t)b * H * W * CB, H, W, y0 - 1, R + 2, x0 - 1, WS + 2, tid);
+        }
+    };
+    auto pf_store = [&]() {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        if constexpr (!UP) {
+            ra.store(tile_a, R + 2, WS + 2, tid);
+        } else {
+            ra.store(tile_a, (R >> 1) + 2, (WS >> 1) + 2, tid);
+            rb.store(tile_b, R + 2, WS + 2, tid);
+        }
+    };
+
+    // HEAD: float4 quads of the state (one Philox counter each), dealt evenly to the four wavefronts
+    struct Quad { int64_t off; int qs; bool act; };
+    auto quad_of = [&](int64_t wg) {
+        Quad q;
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
+        int64_t b; int y0, x0;
+        item(wg, b, y0, x0);
+        const int rowsx = min(min(R, H - y0), a.Hx - y0);
+        const int colsx = min(WS, a.Wx - x0);
+        const int qrow = max(colsx, 0) >> 2, nq = max(rowsx, 0) * qrow, qpw = (nq + 3) >> 2;
+        const int qi = wave * qpw + lane;
+        q.act = lane < qpw && qi < nq;
+        const int qr = qi / max(qrow, 1), qx = qi - qr * qrow;
+        q.qs = qr * WS + qx * 4;
+        q.off = (int64_t)b * a.Hx * a.Wx + (int64_t)(y0 + qr) * a.Wx + x0 + qx * 4;
+        return q;
+    };
+    f32x4 x_next = {0.f, 0.f, 0.f, 0.f};
+    auto x_fetch = [&](int64_t wg) {
+        if constexpr (EPI == SE_HEAD) {
+            const Quad q = quad_of(wg);
+            if (q.act && a.do_update) x_next = *(const f32x4 *)(a.x + q.off);
+        }
+    };
+    auto conv_begin = [&](int64_t wg) {
+        int64_t b; int y0, x0;
+        item(wg, b, y0, x0);
+        cs.begin(tile_a, tile_b, c_b, c_2, geo, 0, min(R, H - y0), (const bf16x8 *)a.w, wave, lane, 1);
+    };
+
+    int64_t wg = blockIdx.x;
+    if (wg < total) {
+        conv_begin(wg);
+        x_fetch(wg);
+        pf_load(wg);
+    }
+    for (; wg < total; wg += gridDim.x) {
+        int64_t b; int y0, x0;
+        item(wg, b, y0, x0);
+        const int rows = min(R, H - y0);
+        const f32x4 x_cur = x_next;
+        (void)x_cur;
+        const int64_t wg_next = wg + gridDim.x < total ? wg + gridDim.x : wg;
+
+        pf_store();
+        __syncthreads();
+
+        if constexpr (EPI == SE_HEAD) {
+            float *score_s = (float *)stage;
+            auto epi = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *kw, int mt, int r, int x, bool valid) {
+                (void)mt;
+                f32x4 p4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                    p4 += silu4(z + kb[g]) * kw[g];
+                }
+                float part = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+                part += __shfl_xor(part, 32, 64);
+                if (valid && h == 0) score_s[r * WS + x] = part + c_bh[0];
+            };
+            cs.run(epi);
+            float zq[4] = {0.f, 0.f, 0.f, 0.f};
+            const Quad q = quad_of(wg);
+            if (a.do_update && a.add_noise && !a.noise && q.act)
+                normal4(a.ph.seed, a.ph.first_global_index + b, (uint32_t)((q.off - (int64_t)b * a.Hx * a.Wx) >> 2), a.ph.t, zq);
+            conv_begin(wg_next);
+            x_fetch(wg_next);
+            pf_load(wg_next);
+            __syncthreads();
+            if (q.act) {
+                const f32x4 sc = *(const f32x4 *)(score_s + q.qs);
+                if (a.score_out) *(f32x4 *)(a.score_out + q.off) = sc;
+                if (a.do_update) {
+                    float z[4] = {zq[0], zq[1], zq[2], zq[3]};
+                    if (a.add_noise && a.noise) {
+                        const f32x4 zv = *(const f32x4 *)(a.noise + q.off);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) z[j] = zv[j];
+                    }
+                    f32x4 xv = x_cur;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = __fadd_rn(__fmul_rn(a.c1, xv[j]), __fmul_rn(a.beta, sc[j]));
+                        if (a.add_noise) v = __fadd_rn(v, __fmul_rn(z[j], a.sd));
+                        xv[j] = v;
+                    }
+                    *(f32x4 *)(a.x + q.off) = xv;
+                }
+            }
+        } else {
+            auto epi = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *kt, int mt, int r, int x, bool valid) {
+                if (!valid) return;
+                char *dst = stage + (r * WS + x) * SO + (mt * 32 + 4 * h) * 2;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                    z = silu4(z + kb[g]);
+                    if constexpr (TADD) z = z + kt[g];
+                    *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
+                }
+            };
+            cs.run(epi);
+            conv_begin(wg_next);
+            pf_load(wg_next);
+            __syncthreads();
+            constexpr int CH = COUT / 8;
+            __bf16 *og = (__bf16 *)a.out + (((size_t)b * H + y0) * W + x0) * COUT;
+            for (int i = tid; i < rows * WS * CH; i += WG) {
+                const int ch = i % CH, pos = i / CH;
+                const int r = pos / WS, xx = pos - r * WS;
+                *(bf16x8 *)(og + ((size_t)r * W + xx) * COUT + ch * 8) = *(const bf16x8 *)(stage + pos * SO + ch * 16);
+            }
+            if constexpr (EPI == SE_STORE_POOL) {
+                const int Wh = W >> 1, wsh = WS >> 1, rh = rows >> 1;
+                __bf16 *pg = (__bf16 *)a.out_pool + (((size_t)b * (H >> 1) + (y0 >> 1)) * Wh + (x0 >> 1)) * COUT;
+                for (int i = tid; i < rh * wsh * CH; i += WG) {
+                    const int ch = i % CH, pos = i / CH;
+                    const int xh = pos % wsh, yh = pos / wsh;
+                    const char *q = stage + ((2 * yh) * WS + 2 * xh) * SO + ch * 16;
+                    const bf16x8 t0 = *(const bf16x8 *)q, t1 = *(const bf16x8 *)(q + SO);
+                    const bf16x8 t2 = *(const bf16x8 *)(q + WS * SO), t3 = *(const bf16x8 *)(q + WS * SO + SO);
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        o[j] = (__bf16)((((float)t0[j] + (float)t1[j]) + (float)t2[j] + (float)t3[j]) * 0.25f);
+                    *(bf16x8 *)(pg + ((size_t)yh * Wh + xh) * COUT + ch * 8) = o;
+                }
+            }
+        }
+        __syncthreads();  // windows and staging consumed before the next item overwrites them
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct StripKind { int ca, cb, up, cout, epi, npa, npb; };
+// npa / npb: 16-byte items per thread the instance can hold for the next item's windows
+constexpr StripKind kStrip[SK_COUNT] = {
+    {32, 0, 0, 32, SE_STORE_POOL, 6, 0},   // SK_CONV1
+    {32, 0, 0, 64, SE_STORE, 6, 0},        // SK_CONV2
+    {64, 0, 0, 64, SE_STORE_POOL, 11, 0},  // SK_CONV3
+    {64, 0, 0, 128, SE_STORE, 11, 0},      // SK_CONV4 (+ time add)
+    {128, 0, 0, 128, SE_STORE, 11, 0},     // SK_CONV5
+    {128, 64, 1, 64, SE_STORE, 7, 11},     // SK_CONV6
+    {64, 0, 0, 64, SE_STORE, 11, 0},       // SK_CONV7
+    {64, 32, 1, 32, SE_STORE, 4, 6},       // SK_CONV8
+    {32, 0, 0, 32, SE_HEAD, 6, 0},         // SK_CONV9 (+ head, update)
+};
+
+inline int a16(int v) { return (v + 15) & ~15; }
+
+struct StripLaunch {
+    bool configured = false;
+    int cus = 0, cached_lds = -1, cached_blocks = 0;
+};
+
+template <class K>
+hipError_t launch_strip_one(StripLaunch &st, K kernel, const StripArgs &a, hipStream_t s)
+{
+    const int lds = a.lds_in_bytes + a.lds_stage_bytes + a.lds_const_bytes;
+    if (!st.configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+        st.cus = prop.multiProcessorCount;
+        st.configured = true;
+    }
+    if (st.cached_lds != lds) {
+        int n = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kernel, WG, (size_t)lds);
+        if (e != hipSuccess) return e;
+        st.cached_blocks = n > 0 ? n : 1;
+        st.cached_lds = lds;
+    }
+    const int64_t total = a.B * a.nbands * a.nstrips;
+    const int64_t grid = std::min<int64_t>(total, (int64_t)st.cus * st.cached_blocks);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WG), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// LDS bytes of one instance for band height R and strip width WS.
+void strip_lds_bytes(int kind, int R, int WS, int *in_bytes, int *stage_bytes, int *const_bytes)
+{
+    const StripKind &k = kStrip[kind];
+    const int sa = k.ca * 2 + 16, sb = k.cb * 2 + 16, so = k.cout * 2 + 16;
+    int in;
+    if (!k.up) in = (R + 2) * (WS + 2) * sa;
+    else in = a16((R / 2 + 2) * (WS / 2 + 2) * sa) + (R + 2) * (WS + 2) * sb;
+    *in_bytes = a16(in);
+    *stage_bytes = a16(k.epi == SE_HEAD ? R * WS * 4 : R * WS * so);
+    *const_bytes = (2 * k.cout + 4) * 4;
+}
+
+// True when the next item's windows fit the instance's prefetch registers.
+bool strip_fits(int kind, int R, int WS)
+{
+    const StripKind &k = kStrip[kind];
+    if (!k.up) return (R + 2) * (WS + 2) * (k.ca / 8) <= k.npa * WG;
+    return (R / 2 + 2) * (WS / 2 + 2) * (k.ca / 8) <= k.npa * WG && (R + 2) * (WS + 2) * (k.cb / 8) <= k.npb * WG;
+}
+
+hipError_t launch_strip(int kind, const StripArgs &a, hipStream_t s)
+{
+    static thread_local StripLaunch st[SK_COUNT];
+    switch (kind) {
+    case SK_CONV1: return launch_strip_one(st[0], strip_kernel<32, 0, false, 32, SE_STORE_POOL, false, 3, 1, 3, 6, 0, 2>, a, s);
+    case SK_CONV2: return launch_strip_one(st[1], strip_kernel<32, 0, false, 64, SE_STORE, false, 3, 1, 3, 6, 0, 2>, a, s);
+    case SK_CONV3: return launch_strip_one(st[2], strip_kernel<64, 0, false, 64, SE_STORE_POOL, false, 3, 1, 3, 11, 0, 2>, a, s);
+    case SK_CONV4: return launch_strip_one(st[3], strip_kernel<64, 0, false, 128, SE_STORE, true, 3, 1, 3, 11, 0, 2>, a, s);
+    case SK_CONV5: return launch_strip_one(st[4], strip_kernel<128, 0, false, 128, SE_STORE, false, 3, 1, 3, 11, 0, 2>, a, s);
+    case SK_CONV6: return launch_strip_one(st[5], strip_kernel<128, 64, true, 64, SE_STORE, false, 3, 1, 3, 7, 11, 2>, a, s);
+    case SK_CONV7: return launch_strip_one(st[6], strip_kernel<64, 0, false, 64, SE_STORE, false, 3, 1, 3, 11, 0, 2>, a, s);
+    case SK_CONV8: return launch_strip_one(st[7], strip_kernel<64, 32, true, 32, SE_STORE, false, 3, 1, 3, 4, 6, 2>, a, s);
+    default: return launch_strip_one(st[8], strip_kernel<32, 0, false, 32, SE_HEAD, false, 3, 1, 3, 6, 0, 2>, a, s);
+    }
+}

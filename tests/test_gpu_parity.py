@@ -97,6 +97,39 @@ def test_bf16_fused_matches_per_layer_kernels(gpu_real, B, H, W, t):
     assert e < BF16_SCORE_TOL, e
 
 
+@pytest.mark.parametrize("B,L,t", [(3, 32, 600), (2, 64, 800), (1, 128, 400)])
+def test_bf16_strip_kernels_match_fused_and_per_layer(gpu_real, B, L, t):
+    """Single-convolution strip kernels (used where a fused band would have to shrink) against the fused
+    bands (forced where possible) and the per-layer kernels, layer by layer; also the in-kernel update."""
+    import torch
+    from isingdiff.sampler import diffusion_backward
+    rng = np.random.default_rng(L + 1)
+    x = ising_like(rng, B, L, L, t)
+    tn = np.float32(t) / np.float32(1000)
+    try:
+        gpu_real.set_option("strip_below_rows", 1000)        # strips wherever a band is not the whole map
+        s, ts = gpu_real.forward_taps(x, tn, precision="bf16")
+        z = rng.standard_normal((1, B, L, L, 1)).astype(np.float32)
+        xs = diffusion_backward(x, np.array([0.013], np.float32), gpu_real, 1, noise=z, precision="bf16",
+                                return_trajectory=False)
+        gpu_real.set_option("strip_below_rows", 0)           # fused bands of any height that fits
+        f, tf_ = gpu_real.forward_taps(x, tn, precision="bf16")
+        gpu_real.set_option("fused", 0)
+        p, tp = gpu_real.forward_taps(x, tn, precision="bf16")
+        xp = diffusion_backward(x, np.array([0.013], np.float32), gpu_real, 1, noise=z, precision="bf16",
+                                return_trajectory=False)
+    finally:
+        gpu_real.set_option("fused", 1)
+        gpu_real.set_option("strip_below_rows", 8)
+    for i in (1, 3, 5, 7):
+        a, b = ts[i].cpu().numpy(), tp[i].cpu().numpy()
+        assert not np.isnan(a).any() and rel_l2(a, b) < 8e-3, f"layer {i}"
+    s, f, p = (v.cpu().numpy() for v in (s, f, p))
+    assert rel_l2(s, p) < BF16_SCORE_TOL and rel_l2(s, f) < BF16_SCORE_TOL
+    xs, xp = (np.asarray(v.cpu() if hasattr(v, "cpu") else v) for v in (xs, xp))
+    assert rel_l2(xs, xp) < 1e-3
+
+
 @pytest.mark.parametrize("L", [64, 128])
 def test_large_lattices(gpu_real, real_spec, ref_real, L):
     """The L=20-trained weights applied convolutionally at L=64 / 128 (BASELINE config 3):

@@ -102,6 +102,8 @@ struct idm_model {
     float *w_head = nullptr;               // (F, C) float32
     void *wpack_f32[IDM_NCONV] = {};       // layers 1..9
     void *wpack_bf16[IDM_NCONV] = {};
+    void *wpack_fold[IDM_NCONV] = {};      // BatchNorm models: bf16 pack of W*scale (strip kernels)
+    float *bias_fold[IDM_NCONV] = {};      // bias*scale + shift
     float *bias[IDM_NCONV] = {};
     float *scale[IDM_NCONV] = {};
     float *shift[IDM_NCONV] = {};
@@ -138,6 +140,7 @@ struct Plan {
     size_t off_a0, off_s1, off_a2, off_s2, off_a4, off_a5, off_a6, off_a7, off_a8, off_a9, off_score, per_lattice;
     bool fused;          // bf16 band kernels usable for this shape
     int R[5];            // band rows per fused kernel
+    bool layers;         // bf16, 2-channel / BatchNorm model: layers 1..9 run as strip kernels (BatchNorm folded)
     bool strip[5];       // this pair of layers runs as single-convolution strip kernels instead
     int sR[SK_COUNT], sWS[SK_COUNT];   // band rows / strip columns of the strip kernels
 };
@@ -173,7 +176,9 @@ int pick_strip_rows(int kind, int H, int W, int *WS)
 {
     const int ws = W < 32 ? W : 32;
     *WS = ws;
-    if (W % ws != 0 || (ws & 3)) return 0;
+    // strips tile the width exactly; pooled / upsampled layers need an even strip, the update float4 quads
+    const bool even = kind == SK_CONV1 || kind == SK_CONV3 || kind == SK_CONV6 || kind == SK_CONV8;
+    if (W % ws != 0 || (even && (ws & 1)) || (kind == SK_CONV9 && (ws & 3))) return 0;
     const int cand[4] = {16, 8, 4, 2};
     for (int i = 0; i < 4; ++i) {
         const int R = cand[i];
@@ -225,6 +230,17 @@ Plan make_plan(const idm_model *m, int H, int W, int precision)
             // full-height fused bands where they fit; strips where the band would have to shrink
             p.strip[k] = ok && (p.R[k] < m->strip_below_rows && p.R[k] < hh[k]);
             if (p.R[k] == 0 && !p.strip[k]) p.fused = false;
+        }
+    }
+    p.layers = false;
+    if (precision == IDM_BF16 && !p.fused && m->use_fused && (m->C == 2 || m->bn)) {
+        const int hh[3] = {p.Hp, p.Hp / 2, p.Hp / 4}, ww[3] = {p.Wp, p.Wp / 2, p.Wp / 4};
+        const int lvl[SK_COUNT] = {0, 1, 1, 2, 2, 1, 1, 0, 0, 0};
+        p.layers = true;
+        for (int sk = SK_CONV1; sk <= SK_CONV9S; ++sk) {
+            if (sk == SK_CONV9) continue;
+            p.sR[sk] = pick_strip_rows(sk, hh[lvl[sk]], ww[lvl[sk]], &p.sWS[sk]);
+            if (p.sR[sk] == 0) p.layers = false;
         }
     }
     return p;
@@ -451,6 +467,42 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
         timed(m, name, 2.0 * 9 * (C0 + C1) * a.Cout * px, px * (in_px * p.es + a.Cout * (out_f32 ? 4 : p.es)), s,
               [&] { if (bf) launch_conv_bf16(a, s); else launch_conv_f32(a, s); });
     };
+    if (bf && p.layers) {
+        // layers 1..9 as strip kernels (BatchNorm folded into weights and bias); pooled maps live in the
+        // buffers of layers that run later (a4 before conv4, a5 before conv5)
+        int rc = IDM_OK;
+        auto strip = [&](int sk, int l, const void *in_a, const void *in_b, void *out, void *out_pool, int H, int W) {
+            if (rc != IDM_OK) return;
+            StripArgs a = {};
+            a.H = H; a.W = W; a.R = p.sR[sk]; a.WS = p.sWS[sk]; a.nbands = H / a.R; a.nstrips = W / a.WS;
+            a.Hx = p.H; a.Wx = p.W; a.B = Bc;
+            a.in_a = in_a; a.in_b = in_b;
+            a.w = m->bn ? m->wpack_fold[l] : m->wpack_bf16[l];
+            a.bias = m->bn ? m->bias_fold[l] : m->bias[l];
+            a.tadd = l == 4 ? tadd : nullptr;
+            a.out = out; a.out_pool = out_pool;
+            strip_lds_bytes(sk, a.R, a.WS, &a.lds_in_bytes, &a.lds_stage_bytes, &a.lds_const_bytes);
+            char name[32];
+            snprintf(name, sizeof(name), "strip_conv%d", l);
+            const double px = (double)Bc * H * W;
+            hipError_t e = hipSuccess;
+            timed(m, name, 2.0 * 9 * m->cin[l] * m->cout[l] * px, px * (m->cin[l] + m->cout[l]) * 2, s,
+                  [&] { e = launch_strip(sk, a, s); });
+            if (e != hipSuccess) rc = fail(IDM_ERR_HIP, std::string("launch ") + name + ": " + hipGetErrorString(e));
+        };
+        strip(SK_CONV1, 1, a0, nullptr, s1, a4, Hp, Wp);
+        strip(SK_CONV2, 2, a4, nullptr, a2, nullptr, Hp / 2, Wp / 2);
+        strip(SK_CONV3, 3, a2, nullptr, s2, a5, Hp / 2, Wp / 2);
+        strip(SK_CONV4, 4, a5, nullptr, a4, nullptr, Hp / 4, Wp / 4);
+        strip(SK_CONV5, 5, a4, nullptr, a5, nullptr, Hp / 4, Wp / 4);
+        strip(SK_CONV6, 6, a5, s2, a6, nullptr, Hp / 2, Wp / 2);
+        strip(SK_CONV7, 7, a6, nullptr, a7, nullptr, Hp / 2, Wp / 2);
+        strip(SK_CONV8, 8, a7, s1, a8, nullptr, Hp, Wp);
+        strip(SK_CONV9S, 9, a8, nullptr, a9, nullptr, Hp, Wp);
+        if (rc != IDM_OK) return rc;
+        timed(m, "head", 2.0 * F * m->C * Bc * p.H * p.W, (double)Bc * p.H * p.W * (F * 2 + m->C * 4), s,
+              [&] { launch_head_bf16(a9, Bc, p.H, p.W, Hp, Wp, F, m->C, m->w_head, m->bias[10], score, s); });
+    } else {
     conv(1, a0, nullptr, F, 0, Hp, Wp, CONV_PLAIN, s1, nullptr, false);
     conv(2, s1, nullptr, F, 0, Hp / 2, Wp / 2, CONV_POOL, a2, nullptr, false);
     conv(3, a2, nullptr, 2 * F, 0, Hp / 2, Wp / 2, CONV_PLAIN, s2, nullptr, false);
@@ -462,6 +514,7 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
     conv(9, a8, nullptr, F, 0, Hp, Wp, CONV_PLAIN, a9, nullptr, true);
     timed(m, "head", 2.0 * F * m->C * Bc * p.H * p.W, (double)Bc * p.H * p.W * (F * 4 + m->C * 4), s,
           [&] { launch_head(a9, Bc, p.H, p.W, Hp, Wp, F, m->C, m->w_head, m->bias[10], score, s); });
+    }
 
     if (taps) {
         const size_t n1 = (size_t)Hp * Wp, n2 = n1 / 4, n4 = n1 / 16;
@@ -470,7 +523,7 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
         for (int i = 0; i < 10; ++i) {
             if (!taps[i]) continue;
             float *dst = taps[i] + (size_t)tap_b0 * cnt[i];
-            if (bf && i != 9) launch_cast_bf16_to_f32(src[i], dst, (int64_t)(cnt[i] * Bc), s);
+            if (bf && (i != 9 || p.layers)) launch_cast_bf16_to_f32(src[i], dst, (int64_t)(cnt[i] * Bc), s);
             else HIPCHK(hipMemcpyAsync(dst, src[i], cnt[i] * Bc * 4, hipMemcpyDeviceToDevice, s));
         }
         if (taps[10]) {
@@ -544,6 +597,15 @@ int idm_model_create(idm_model **out, int device, const idm_model_desc *d)
             std::vector<float> pf = pack_weights_f32(d->conv_w[i], cin[i], cout[i]);
             rc = upload(m, pb.data(), pb.size(), (uint16_t **)&m->wpack_bf16[i]);
             if (rc == IDM_OK) rc = upload(m, pf.data(), pf.size(), (float **)&m->wpack_f32[i]);
+            if (rc == IDM_OK && m->bn) {
+                // inference BatchNorm folded into the convolution: (W x + b)*s + h = (W*s) x + (b*s + h)
+                std::vector<float> wf((size_t)9 * cin[i] * cout[i]), bf_(cout[i]);
+                for (size_t k = 0; k < wf.size(); ++k) wf[k] = d->conv_w[i][k] * d->bn_scale[i][k % cout[i]];
+                for (int k = 0; k < cout[i]; ++k) bf_[k] = d->conv_b[i][k] * d->bn_scale[i][k] + d->bn_shift[i][k];
+                std::vector<uint16_t> pfold = pack_weights_bf16(wf.data(), cin[i], cout[i]);
+                rc = upload(m, pfold.data(), pfold.size(), (uint16_t **)&m->wpack_fold[i]);
+                if (rc == IDM_OK) rc = upload(m, bf_.data(), bf_.size(), &m->bias_fold[i]);
+            }
         }
     }
     const int din[IDM_NDENSE] = {1, 4 * f, 4 * f};

@@ -198,7 +198,8 @@ void launch_conv_first(const float *x, int64_t B, int H, int W, int Hp, int Wp, 
 }
 
 // Head: 1x1 conv F -> C (linear) on the float32 output of the last 3x3 layer, cropped to (H,W).
-__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ a9, int64_t B, int H, int W, int Hp, int Wp,
+template <typename InT>
+__global__ __launch_bounds__(256) void head_kernel(const InT *__restrict__ a9, int64_t B, int H, int W, int Hp, int Wp,
                                                    int F, int C, const float *__restrict__ w,
                                                    const float *__restrict__ bias, float *__restrict__ score)
 {
@@ -206,10 +207,10 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ a9,
     if (p >= B * H * W) return;
     const int x = (int)(p % W), y = (int)((p / W) % H);
     const int64_t b = p / ((int64_t)W * H);
-    const float *ip = a9 + ((b * Hp + y) * Wp + x) * F;
+    const InT *ip = a9 + ((b * Hp + y) * Wp + x) * F;
     for (int ch = 0; ch < C; ++ch) {
         float acc = 0.0f;
-        for (int f = 0; f < F; ++f) acc = __fmaf_rn(ip[f], w[f * C + ch], acc);
+        for (int f = 0; f < F; ++f) acc = __fmaf_rn((float)ip[f], w[f * C + ch], acc);
         score[p * C + ch] = __fadd_rn(acc, bias[ch]);
     }
 }
@@ -218,7 +219,15 @@ void launch_head(const float *a9, int64_t B, int H, int W, int Hp, int Wp, int F
                  const float *bias, float *score, hipStream_t s)
 {
     const unsigned grid = (unsigned)((B * H * W + 255) / 256);
-    hipLaunchKernelGGL(head_kernel, dim3(grid), dim3(256), 0, s, a9, B, H, W, Hp, Wp, F, C, w, bias, score);
+    hipLaunchKernelGGL(head_kernel<float>, dim3(grid), dim3(256), 0, s, a9, B, H, W, Hp, Wp, F, C, w, bias, score);
+}
+
+void launch_head_bf16(const void *a9, int64_t B, int H, int W, int Hp, int Wp, int F, int C, const float *w,
+                      const float *bias, float *score, hipStream_t s)
+{
+    const unsigned grid = (unsigned)((B * H * W + 255) / 256);
+    hipLaunchKernelGGL(head_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16 *)a9, B, H, W, Hp, Wp, F, C, w, bias,
+                       score);
 }
 
 // x <- ((c1*x) + (beta*score)) + z*sqrt(beta).  One thread per quad of four consecutive elements.

@@ -56,6 +56,8 @@ void launch_conv_first(const float *x, int64_t B, int H, int W, int Hp, int Wp, 
                        bool out_bf16, hipStream_t s);
 void launch_head(const float *a9, int64_t B, int H, int W, int Hp, int Wp, int F, int C, const float *w,
                  const float *bias, float *score, hipStream_t s);
+void launch_head_bf16(const void *a9, int64_t B, int H, int W, int Hp, int Wp, int F, int C, const float *w,
+                      const float *bias, float *score, hipStream_t s);
 void launch_update(float *x, const float *score, const float *z, float beta, int64_t n_lattices,
                    int64_t elems, bool add_noise, const PhiloxArgs &ph, hipStream_t s);
 void launch_philox_normal(float *out, int64_t n_lattices, int64_t elems, const PhiloxArgs &ph, hipStream_t s);
@@ -107,7 +109,7 @@ bool fused_band_fits(int kind, int W, int R);
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s);
 
 // ---- single-convolution band/strip kernels (idm_strip.hip) ----
-enum StripKindId { SK_CONV1 = 0, SK_CONV2, SK_CONV3, SK_CONV4, SK_CONV5, SK_CONV6, SK_CONV7, SK_CONV8, SK_CONV9, SK_COUNT };
+enum StripKindId { SK_CONV1 = 0, SK_CONV2, SK_CONV3, SK_CONV4, SK_CONV5, SK_CONV6, SK_CONV7, SK_CONV8, SK_CONV9, SK_CONV9S, SK_COUNT };   // SK_CONV9: conv9 + head + update; SK_CONV9S: conv9 stored
 
 struct StripArgs {
     int H, W;          // map size of this layer's output (= its full-resolution input)

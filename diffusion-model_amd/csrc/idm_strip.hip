@@ -282,6 +282,7 @@ constexpr StripKind kStrip[SK_COUNT] = {
     {64, 0, 0, 64, SE_STORE, 11, 0},       // SK_CONV7
     {64, 32, 1, 32, SE_STORE, 4, 6},       // SK_CONV8
     {32, 0, 0, 32, SE_HEAD, 6, 0},         // SK_CONV9 (+ head, update)
+    {32, 0, 0, 32, SE_STORE, 6, 0},        // SK_CONV9S
 };
 
 inline int a16(int v) { return (v + 15) & ~15; }
@@ -352,6 +353,7 @@ hipError_t launch_strip(int kind, const StripArgs &a, hipStream_t s)
     case SK_CONV6: return launch_strip_one(st[5], strip_kernel<128, 64, true, 64, SE_STORE, false, 3, 1, 3, 7, 11, 2>, a, s);
     case SK_CONV7: return launch_strip_one(st[6], strip_kernel<64, 0, false, 64, SE_STORE, false, 3, 1, 3, 11, 0, 2>, a, s);
     case SK_CONV8: return launch_strip_one(st[7], strip_kernel<64, 32, true, 32, SE_STORE, false, 3, 1, 3, 4, 6, 2>, a, s);
-    default: return launch_strip_one(st[8], strip_kernel<32, 0, false, 32, SE_HEAD, false, 3, 1, 3, 6, 0, 2>, a, s);
+    case SK_CONV9: return launch_strip_one(st[8], strip_kernel<32, 0, false, 32, SE_HEAD, false, 3, 1, 3, 6, 0, 2>, a, s);
+    default: return launch_strip_one(st[9], strip_kernel<32, 0, false, 32, SE_STORE, false, 3, 1, 3, 6, 0, 2>, a, s);
     }
 }

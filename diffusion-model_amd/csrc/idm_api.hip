@@ -800,6 +800,18 @@ int idm_irfft2_sign(int device, const float *spec_dev, int64_t B, int L, int8_t 
     return IDM_OK;
 }
 
+int idm_metropolis(int device, int8_t *spins_dev, int64_t B, int L, const float *accept_host, int n_sweeps, uint64_t seed,
+                   int64_t first_global_index, int sweep0, void *stream)
+{
+    if (!spins_dev || !accept_host || B <= 0 || n_sweeps < 0) return fail(IDM_ERR_INVALID, "bad argument");
+    if (L < 2 || (L & 1) || L > 224) return fail(IDM_ERR_UNSUPPORTED, "checkerboard Metropolis needs an even L in [2, 224]");
+    HIPCHK(hipSetDevice(device));
+    PhiloxArgs ph = {seed, first_global_index, 0};
+    launch_metropolis(spins_dev, B, L, accept_host, n_sweeps, ph, sweep0, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return IDM_OK;
+}
+
 int idm_set_option(idm_model *m, const char *name, int value)
 {
     if (!m || !name) return fail(IDM_ERR_INVALID, "null argument");

@@ -468,3 +468,52 @@ hipError_t launch_irfft2_sign(const float *spec, int64_t B, int L, int8_t *spins
     hipLaunchKernelGGL(irfft2_sign_kernel, dim3((unsigned)B), dim3(256), lds, s, spec, L, spins, real_out);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Checkerboard Metropolis generator (acceptance rule of b_pure_metoropolis_2d_ising.py:35-38).
+// One workgroup per chain, the lattice lives in LDS for all sweeps.  Colour c of sweep w updates the
+// sites with (row + col) % 2 == c; the k-th such site draws component k % 4 of Philox with counter
+// (k / 4, chain lo, chain hi, 2w + c); it flips when u < table[(s+1)/2][(nn+4)/2].
+// ---------------------------------------------------------------------------------------------
+struct MetroTable { float t[10]; };
+
+__global__ __launch_bounds__(256) void metropolis_kernel(int8_t *__restrict__ spins, int L, MetroTable tab, int n_sweeps,
+                                                         PhiloxArgs ph, int sweep0)
+{
+    extern __shared__ int8_t lat[];
+    const int64_t b = blockIdx.x;
+    int8_t *x = spins + b * L * L;
+    for (int i = threadIdx.x; i < L * L; i += 256) lat[i] = x[i];
+    __syncthreads();
+    const int64_t g = ph.first_global_index + b;
+    const int half = L >> 1, ngroups = (L * half + 3) >> 2;
+    for (int w = sweep0; w < sweep0 + n_sweeps; ++w)
+        for (int c = 0; c < 2; ++c) {
+            for (int q = threadIdx.x; q < ngroups; q += 256) {
+                uint32_t r4[4];
+                philox4x32_10((uint32_t)q, (uint32_t)g, (uint32_t)((uint64_t)g >> 32), (uint32_t)(2 * w + c), (uint32_t)ph.seed,
+                              (uint32_t)(ph.seed >> 32), r4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = q * 4 + j;
+                    if (k >= L * half) break;
+                    const int r = k / half, col = 2 * (k - r * half) + ((r + c) & 1);
+                    const int rp = r + 1 == L ? 0 : r + 1, rm = r == 0 ? L - 1 : r - 1;
+                    const int cp = col + 1 == L ? 0 : col + 1, cm = col == 0 ? L - 1 : col - 1;
+                    const int s = lat[r * L + col];
+                    const int nn = lat[rp * L + col] + lat[rm * L + col] + lat[r * L + cp] + lat[r * L + cm];
+                    if (u01(r4[j]) < tab.t[((s + 1) >> 1) * 5 + ((nn + 4) >> 1)]) lat[r * L + col] = (int8_t)-s;
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < L * L; i += 256) x[i] = lat[i];
+}
+
+void launch_metropolis(int8_t *spins, int64_t B, int L, const float *table10, int n_sweeps, const PhiloxArgs &ph, int sweep0,
+                       hipStream_t s)
+{
+    MetroTable t;
+    for (int i = 0; i < 10; ++i) t.t[i] = table10[i];
+    hipLaunchKernelGGL(metropolis_kernel, dim3((unsigned)B), dim3(256), (size_t)L * L, s, spins, L, t, n_sweeps, ph, sweep0);
+}

@@ -83,6 +83,8 @@ SIGNATURES = {
     "idm_observe": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_void_p]),
     "idm_irfft2_sign": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "idm_metropolis": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_int,
+                                 C.c_void_p]),
     "idm_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "idm_profile_begin": (C.c_int, [C.c_void_p]),
     "idm_profile_end": (C.c_int, [C.c_void_p, C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),

@@ -145,6 +145,16 @@ int idm_observe(int device, const int8_t *spins_dev, int64_t B, int L, int32_t *
 int idm_irfft2_sign(int device, const float *spec_dev, int64_t B, int L, int8_t *spins_dev, double *real_dev,
                     void *stream);
 
+/* Ising configurations at inverse temperature beta: checkerboard Metropolis sweeps with the acceptance
+ * rule of pure_metropolis_next (b_pure_metoropolis_2d_ising.py:35-38): flip when u < exp(-beta*dE),
+ * dE = 2 s (J*sum_nn + h), periodic boundaries.  The reference flips one random site at a time from
+ * numpy's global RNG; here the two colours are swept in turn with Philox uniforms (same stationary
+ * distribution, one independent chain per lattice).  spins_dev (B,L,L) int8 in/out, L even;
+ * accept_host: 10 float32 = exp(-beta*dE) for s in {-1,+1} x sum_nn in {-4,-2,0,2,4} (row-major);
+ * sweep0: index of the first sweep (continue a chain with sweep0 += n_sweeps). */
+int idm_metropolis(int device, int8_t *spins_dev, int64_t B, int L, const float *accept_host, int n_sweeps,
+                   uint64_t seed, int64_t first_global_index, int sweep0, void *stream);
+
 /* Tuning switches (no counterpart in the reference).  "fused" (default 1): bf16 forward uses
  * the fused two-convolution band kernels when the shape fits; 0 forces one kernel per layer. */
 int idm_set_option(idm_model *m, const char *name, int value);

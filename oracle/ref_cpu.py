@@ -18,7 +18,7 @@ _LIB = None
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libref_cpu.so")
-    srcs = [os.path.join(_HERE, n) for n in ("ref_cpu.c", "ref_bitflip.c")]
+    srcs = [os.path.join(_HERE, n) for n in ("ref_cpu.c", "ref_bitflip.c", "ref_mlp.c", "ref_metropolis.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
@@ -279,3 +279,14 @@ class RefDense:
         lib().ref_mlp_sample(self.nl, self.ind, self.outd, self.act, _ptr_array(self.k), _ptr_array(self.b), _ptr(x),
                              _ptr(betas), T, _ptr(z), _ptr(traj), x.shape[0])
         return (x, traj) if trajectory else x
+
+
+def metropolis(spins, table, n_sweeps, seed=42, first_global_index=0, sweep0=0):
+    """Checkerboard Metropolis sweeps of ``ref_metropolis.c`` on (B,L,L) int8 spins (returns a copy)."""
+    x = np.array(spins, np.int8, order="C")
+    B, L, _ = x.shape
+    t = np.ascontiguousarray(table, np.float32).reshape(2, 5)
+    L_ = lib()
+    L_.ref_metropolis.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_int]
+    L_.ref_metropolis(_ptr(x), B, L, _ptr(t), n_sweeps, seed, first_global_index, sweep0)
+    return x

@@ -165,14 +165,18 @@ extern "C" int idm_debug_timeline(long long *host)
 // and, where conv2's weights fit in registers as a whole (WD2 >= its supersteps), the next band's
 // input is requested even before conv2.
 // OCC: wavefronts per SIMD the register budget is sized for (= workgroups per CU when LDS allows).
-template <int MODE1, int CA, int CB, int C1, int C2, int EPI2, bool TADD, int NT1, int MS1, int WD1, int NT2, int MS2, int WD2, int NPA, int NPB, int OCC>
+// WT, RT: map width and band rows as compile-time constants (0 = taken from the arguments); the
+// specialised instances turn the index arithmetic of the tile copies into shifts and immediates.
+template <int MODE1, int CA, int CB, int C1, int C2, int EPI2, bool TADD, int NT1, int MS1, int WD1, int NT2, int MS2, int WD2, int NPA, int NPB, int OCC, int WT, int RT>
 __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = tid >> 6;
     const int h = lane >> 5;
-    const int W = a.W, H = a.H, R = a.R;
+    const int W = WT ? WT : a.W, H = a.H, R = RT ? RT : a.R;
+    const int Hx = WT ? 32 : a.Hx, Wx = WT ? 32 : a.Wx;   // specialised instances: the L = 32 lattice
+    (void)Hx; (void)Wx;
     constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16, SM = C1 * 2 + 16, SO = C2 * 2 + 16;
     constexpr int CAT = MODE1 == M1_FIRST ? 8 : CA, CBT = MODE1 == M1_UPCAT ? CB : 8;
     (void)SA; (void)SB; (void)SO;
@@ -223,11 +227,11 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
         const int64_t b = wg / a.nbands;
         const int y0 = (int)(wg - b * a.nbands) * R;
         if constexpr (MODE1 == M1_FIRST) {
-            const float *x = (const float *)a.in_a + (size_t)b * a.Hx * a.Wx;
+            const float *x = (const float *)a.in_a + (size_t)b * Hx * Wx;
 #pragma unroll
             for (int k = 0; k < NPA; ++k) {
                 const int i = tid + k * WG, t = i / W, c = i - t * W, g = y0 - 2 + t;
-                rx[k] = (t < R + 4 && g >= 0 && g < a.Hx && c < a.Wx) ? x[(size_t)g * a.Wx + c] : 0.0f;
+                rx[k] = (t < R + 4 && g >= 0 && g < Hx && c < Wx) ? x[(size_t)g * Wx + c] : 0.0f;
             }
         } else if constexpr (MODE1 == M1_PLAIN) {
             ra.load((const __bf16 *)a.in_a + (size_t)b * H * W * CA, H, W, y0 - 2, R + 4, tid);
@@ -282,14 +286,14 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
             mine |= light && w == wave;
             nl += light;
         }
-        const int rowsx = min(min(R, H - y0), a.Hx - y0);
-        const int qrow = a.Wx >> 2, nq = max(rowsx, 0) * qrow, qpw = (nq + nl - 1) / nl;
-        q.path = (a.Wx & 3) == 0 && qpw <= 64;
+        const int rowsx = min(min(R, H - y0), Hx - y0);
+        const int qrow = Wx >> 2, nq = max(rowsx, 0) * qrow, qpw = (nq + nl - 1) / nl;
+        q.path = WT ? true : ((Wx & 3) == 0 && qpw <= 64);
         const int qi = lr * qpw + lane;
         q.act = q.path && mine && lane < qpw && qi < nq;
         const int qr = qi / max(qrow, 1), qx = qi - qr * qrow;
         q.qs = qr * W + qx * 4;                                        // offset in the LDS score tile
-        q.off = (int64_t)b * a.Hx * a.Wx + (y0 + qr) * a.Wx + qx * 4;  // offset in x / score / noise
+        q.off = (int64_t)b * Hx * Wx + (y0 + qr) * Wx + qx * 4;  // offset in x / score / noise
         return q;
     };
     f32x4 x_next = {0.f, 0.f, 0.f, 0.f};
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
             if (a.do_update && a.add_noise && !a.noise) {
                 const Quad q = quad_of(wg);
                 if (q.act) {
-                    const int64_t lat = (int64_t)b * a.Hx * a.Wx;
+                    const int64_t lat = (int64_t)b * Hx * Wx;
                     normal4(a.ph.seed, a.ph.first_global_index + b, (uint32_t)((q.off - lat) >> 2), a.ph.t, zq);
                 }
             }
@@ -428,12 +432,12 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
                     }
                 }
             } else {
-                const int rowsx = min(rows2, a.Hx - y0);
-                float *xg = a.x + (size_t)b * a.Hx * a.Wx;
-                const size_t lat_off = (size_t)b * a.Hx * a.Wx;
-                for (int i = tid; i < rowsx * a.Wx; i += WG) {
-                    const int r = i / a.Wx, xc = i - r * a.Wx;
-                    const int e = (y0 + r) * a.Wx + xc;
+                const int rowsx = min(rows2, Hx - y0);
+                float *xg = a.x + (size_t)b * Hx * Wx;
+                const size_t lat_off = (size_t)b * Hx * Wx;
+                for (int i = tid; i < rowsx * Wx; i += WG) {
+                    const int r = i / Wx, xc = i - r * Wx;
+                    const int e = (y0 + r) * Wx + xc;
                     const float sc = score_s[r * W + xc];
                     if (a.score_out) a.score_out[lat_off + e] = sc;
                     if (!a.do_update) continue;
@@ -596,12 +600,24 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
 
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
 {
-    static thread_local LaunchState st[5];
+    static thread_local LaunchState st[10];
+    // instances specialised for the L = 32 pyramid (widths 32 / 16 / 8, 8-row bands, no padding)
+    const int w32[5] = {32, 16, 8, 16, 32};
+    const bool spec = a.W == w32[kind] && a.R == 8 && a.Hx == 32 && a.Wx == 32;
+    if (spec) {
+        switch (kind) {
+        case FK_A: return launch_one(st[5], fused2_kernel<M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, false, IDM_CFG_A, 32, 8>, a, B, s);
+        case FK_M1: return launch_one(st[6], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1, 16, 8>, a, B, s);
+        case FK_M2: return launch_one(st[7], fused2_kernel<M1_PLAIN, 64, 0, 128, 128, E2_STORE, true, IDM_CFG_M2, 8, 8>, a, B, s);
+        case FK_M3: return launch_one(st[8], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, IDM_CFG_M3, 16, 8>, a, B, s);
+        default: return launch_one(st[9], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, IDM_CFG_B, 32, 8>, a, B, s);
+        }
+    }
     switch (kind) {
-    case FK_A: return launch_one(st[0], fused2_kernel<M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, false, IDM_CFG_A>, a, B, s);
-    case FK_M1: return launch_one(st[1], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1>, a, B, s);
-    case FK_M2: return launch_one(st[2], fused2_kernel<M1_PLAIN, 64, 0, 128, 128, E2_STORE, true, IDM_CFG_M2>, a, B, s);
-    case FK_M3: return launch_one(st[3], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, IDM_CFG_M3>, a, B, s);
-    default: return launch_one(st[4], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, IDM_CFG_B>, a, B, s);
+    case FK_A: return launch_one(st[0], fused2_kernel<M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, false, IDM_CFG_A, 0, 0>, a, B, s);
+    case FK_M1: return launch_one(st[1], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1, 0, 0>, a, B, s);
+    case FK_M2: return launch_one(st[2], fused2_kernel<M1_PLAIN, 64, 0, 128, 128, E2_STORE, true, IDM_CFG_M2, 0, 0>, a, B, s);
+    case FK_M3: return launch_one(st[3], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, IDM_CFG_M3, 0, 0>, a, B, s);
+    default: return launch_one(st[4], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, IDM_CFG_B, 0, 0>, a, B, s);
     }
 }

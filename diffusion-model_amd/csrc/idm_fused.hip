@@ -180,7 +180,16 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
     constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16, SM = C1 * 2 + 16, SO = C2 * 2 + 16;
     constexpr int CAT = MODE1 == M1_FIRST ? 8 : CA, CBT = MODE1 == M1_UPCAT ? CB : 8;
     (void)SA; (void)SB; (void)SO;
-    const int64_t total = a.B * a.nbands;
+    // work items are indexed in 32 bits (the host checks B * nbands < 2^31); specialised instances know nbands
+    const int nbands = (WT && RT) ? WT / RT : a.nbands;
+    const int total = (int)a.B * nbands;
+    struct Item { int b, y0; };
+    auto item_of = [&](int wg) {
+        Item it;
+        it.b = wg / nbands;
+        it.y0 = (wg - it.b * nbands) * R;
+        return it;
+    };
 #ifdef IDM_TIMELINE
     constexpr int TLK = MODE1 == M1_FIRST ? 0 : MODE1 == M1_PLAIN ? (CA == 32 ? 1 : 2) : (CA == 128 ? 3 : 4);
     int tl_it = 0;
@@ -221,11 +230,10 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
 
     // (the thread index is made opaque per call: otherwise the per-item index arithmetic of the
     // tile copies is hoisted out of the band loop and held in registers across the convolutions)
-    auto pf_load = [&](int64_t wg) {
+    auto pf_load = [&](Item it) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        const int64_t b = wg / a.nbands;
-        const int y0 = (int)(wg - b * a.nbands) * R;
+        const int b = it.b, y0 = it.y0;
         if constexpr (MODE1 == M1_FIRST) {
             const float *x = (const float *)a.in_a + (size_t)b * Hx * Wx;
 #pragma unroll
@@ -264,12 +272,11 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
     // are dealt to the wavefronts with the fewest conv1 rows (all four when the split is even):
     // those draw the band's noise right after their conv1 share, while the others still compute.
     struct Quad { int64_t off; int qs; bool act, path; };
-    auto quad_of = [&](int64_t wg) {
+    auto quad_of = [&](Item it) {
         Quad q;
         int lane = threadIdx.x & 63;
         asm volatile("" : "+v"(lane));
-        const int64_t b = wg / a.nbands;
-        const int y0 = (int)(wg - b * a.nbands) * R;
+        const int b = it.b, y0 = it.y0;
         const int rlo = y0 == 0 ? 1 : 0, rhi = min(R + 2, H - y0 + 1);
         const int tot = Conv1::NSL * geo.ncb * ((rhi - rlo + geo.TR - 1) / geo.TR);
         int len[4], mn = 1 << 30;
@@ -297,38 +304,37 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
         return q;
     };
     f32x4 x_next = {0.f, 0.f, 0.f, 0.f};
-    auto x_fetch = [&](int64_t wg) {
+    auto x_fetch = [&](Item it) {
         if constexpr (EPI2 == E2_HEAD) {
-            const Quad q = quad_of(wg);
+            const Quad q = quad_of(it);
             if (q.act && a.do_update) x_next = *(const f32x4 *)(a.x + q.off);
         }
     };
-    auto band_geo = [&](int64_t wg, int &y0, int &rlo, int &rhi) {
-        const int64_t b = wg / a.nbands;
-        y0 = (int)(wg - b * a.nbands) * R;
-        rlo = y0 == 0 ? 1 : 0;
-        rhi = min(R + 2, H - y0 + 1);
+    auto band_geo = [&](Item it, int &rlo, int &rhi) {
+        rlo = it.y0 == 0 ? 1 : 0;
+        rhi = min(R + 2, H - it.y0 + 1);
     };
-    auto conv1_begin = [&](int64_t wg) {
+    auto conv1_begin = [&](Item it) {
         if constexpr (MODE1 != M1_FIRST) {
-            int y0, rlo, rhi;
-            band_geo(wg, y0, rlo, rhi);
+            int rlo, rhi;
+            band_geo(it, rlo, rhi);
             cs1.begin(tile_a, tile_b, c_b1, c_t1, geo, rlo, rhi - rlo, (const bf16x8 *)a.w1, wave, lane);
         }
     };
 
     clear_halo<C1>(lds_mid, W, R + 2, 0, 0, tid);  // halo columns of the mid tile: never written afterwards
-    int64_t wg = blockIdx.x;
+    int wg = blockIdx.x;
+    Item cur = item_of(wg < total ? wg : 0);
     if (wg < total) {
-        conv1_begin(wg);
-        x_fetch(wg);
-        pf_load(wg);
+        conv1_begin(cur);
+        x_fetch(cur);
+        pf_load(cur);
     }
 
     for (; wg < total; wg += gridDim.x) {
-        const int64_t b = wg / a.nbands;
-        int y0, rlo, rhi;
-        band_geo(wg, y0, rlo, rhi);
+        const int b = cur.b, y0 = cur.y0;
+        int rlo, rhi;
+        band_geo(cur, rlo, rhi);
         const f32x4 x_cur = x_next;
         (void)x_cur;
 
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
         float zq[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (EPI2 == E2_HEAD) {
             if (a.do_update && a.add_noise && !a.noise) {
-                const Quad q = quad_of(wg);
+                const Quad q = quad_of(cur);
                 if (q.act) {
                     const int64_t lat = (int64_t)b * Hx * Wx;
                     normal4(a.ph.seed, a.ph.first_global_index + b, (uint32_t)((q.off - lat) >> 2), a.ph.t, zq);
@@ -377,11 +383,11 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
         const int npix2 = rows2 * W;
         // the last iteration reloads its own band (discarded): an unconditional load keeps the prefetch
         // registers dead across the convolutions instead of loop-carried
-        const int64_t wg_next = wg + gridDim.x < total ? wg + gridDim.x : wg;
+        const Item nxt = item_of(wg + (int)gridDim.x < total ? wg + (int)gridDim.x : wg);
         cs2.begin(lds_mid, nullptr, c_b2, c_wh, geo, 0, rows2, (const bf16x8 *)a.w2, wave, lane);
         if constexpr (EARLY_PF) {
-            x_fetch(wg_next);
-            pf_load(wg_next);
+            x_fetch(nxt);
+            pf_load(nxt);
         }
         __syncthreads();
         TL(4);
@@ -401,15 +407,15 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
             };
             cs2.run(epi2);
             TL(5);
-            conv1_begin(wg_next);
+            conv1_begin(nxt);
             if constexpr (!EARLY_PF) {
-                x_fetch(wg_next);
-                pf_load(wg_next);
+                x_fetch(nxt);
+                pf_load(nxt);
             }
             __syncthreads();
             TL(6);
 
-            const Quad q = quad_of(wg);
+            const Quad q = quad_of(cur);
             if (q.path) {
                 if (q.act) {
                     f32x4 sc = *(const f32x4 *)(score_s + q.qs);
@@ -469,8 +475,8 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
             };
             cs2.run(epi2);
             TL(5);
-            conv1_begin(wg_next);
-            if constexpr (!EARLY_PF) pf_load(wg_next);
+            conv1_begin(nxt);
+            if constexpr (!EARLY_PF) pf_load(nxt);
             __syncthreads();
             TL(6);
             constexpr int CH = C2 / 8;
@@ -499,6 +505,7 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
         TL(7);
         __syncthreads();  // staging / score consumed before the next band's input overwrites the region
         TL(8);
+        cur = nxt;
 #ifdef IDM_TIMELINE
         ++tl_it;
 #endif
@@ -576,6 +583,7 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
         st.cached_lds = lds;
     }
     const int64_t total = B * a.nbands;
+    if (total >= ((int64_t)1 << 31)) return hipErrorInvalidValue;   // the kernels index work items in 32 bits
     const int64_t grid = std::min<int64_t>(total, (int64_t)st.cus * st.cached_blocks);
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WG), lds, s, a);
     return hipGetLastError();

@@ -63,16 +63,18 @@ struct WinRegs {
 // item -> (lattice, band, strip) with the strip index fastest, so neighbouring workgroups share
 // their halo columns in L2.  Ordering of vector-memory traffic as in the fused kernels: the next
 // item's first weights are requested before its input, and both before the copy-out.
-template <int CA, int CB, bool UP, int COUT, int EPI, bool TADD, int NT, int MS, int WD, int NPA, int NPB, int OCC>
+// WST, RT: strip width and band rows as compile-time constants (0 = taken from the arguments).
+template <int CA, int CB, bool UP, int COUT, int EPI, bool TADD, int NT, int MS, int WD, int NPA, int NPB, int OCC, int WST, int RT>
 __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5;
-    const int W = a.W, H = a.H, R = a.R, WS = a.WS;
+    const int W = a.W, H = a.H, R = RT ? RT : a.R, WS = WST ? WST : a.WS;
     constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16, SO = COUT * 2 + 16;
     (void)SB; (void)SO;
-    const int64_t per_lat = (int64_t)a.nbands * a.nstrips, total = a.B * per_lat;
+    // work items are indexed in 32 bits (checked on the host)
+    const int per_lat = a.nbands * a.nstrips, total = (int)a.B * per_lat;
 
     // LDS map: [window a | window b | output staging | epilogue constants]
     char *tile_a = smem;
@@ -96,19 +98,19 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
     WinRegs<UP ? CB : 8, UP ? NPB : 1> rb;
     (void)rb;
 
-    auto item = [&](int64_t wg, int64_t &b, int &y0, int &x0) {
+    auto item = [&](int wg, int &b, int &y0, int &x0) {
         b = wg / per_lat;
-        const int r = (int)(wg - b * per_lat);
+        const int r = wg - b * per_lat;
         const int band = r / a.nstrips;
         y0 = band * R;
         x0 = (r - band * a.nstrips) * WS;
     };
     // (the thread index is made opaque per call so that the per-item index arithmetic of the window
     // copies is recomputed per work item instead of being held in registers across the convolution)
-    auto pf_load = [&](int64_t wg) {
+    auto pf_load = [&](int wg) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        int64_t b; int y0, x0;
+        int b, y0, x0;
         item(wg, b, y0, x0);
         if constexpr (!UP) {
             ra.load((const __bf16 *)a.in_a + (size_t)b * H * W * CA, H, W, y0 - 1, R + 2, x0 - 1, WS + 2, tid);
@@ -132,11 +134,11 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
 
     // HEAD: float4 quads of the state (one Philox counter each), dealt evenly to the four wavefronts
     struct Quad { int64_t off; int qs; bool act; };
-    auto quad_of = [&](int64_t wg) {
+    auto quad_of = [&](int wg) {
         Quad q;
         int lane = threadIdx.x & 63;
         asm volatile("" : "+v"(lane));
-        int64_t b; int y0, x0;
+        int b, y0, x0;
         item(wg, b, y0, x0);
         const int rowsx = min(min(R, H - y0), a.Hx - y0);
         const int colsx = min(WS, a.Wx - x0);
@@ -149,31 +151,31 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
         return q;
     };
     f32x4 x_next = {0.f, 0.f, 0.f, 0.f};
-    auto x_fetch = [&](int64_t wg) {
+    auto x_fetch = [&](int wg) {
         if constexpr (EPI == SE_HEAD) {
             const Quad q = quad_of(wg);
             if (q.act && a.do_update) x_next = *(const f32x4 *)(a.x + q.off);
         }
     };
-    auto conv_begin = [&](int64_t wg) {
-        int64_t b; int y0, x0;
+    auto conv_begin = [&](int wg) {
+        int b, y0, x0;
         item(wg, b, y0, x0);
         cs.begin(tile_a, tile_b, c_b, c_2, geo, 0, min(R, H - y0), (const bf16x8 *)a.w, wave, lane, 1);
     };
 
-    int64_t wg = blockIdx.x;
+    int wg = blockIdx.x;
     if (wg < total) {
         conv_begin(wg);
         x_fetch(wg);
         pf_load(wg);
     }
     for (; wg < total; wg += gridDim.x) {
-        int64_t b; int y0, x0;
+        int b, y0, x0;
         item(wg, b, y0, x0);
         const int rows = min(R, H - y0);
         const f32x4 x_cur = x_next;
         (void)x_cur;
-        const int64_t wg_next = wg + gridDim.x < total ? wg + gridDim.x : wg;
+        const int wg_next = wg + (int)gridDim.x < total ? wg + (int)gridDim.x : wg;
 
         pf_store();
         __syncthreads();
@@ -313,6 +315,7 @@ hipError_t launch_strip_one(StripLaunch &st, K kernel, const StripArgs &a, hipSt
         st.cached_lds = lds;
     }
     const int64_t total = a.B * a.nbands * a.nstrips;
+    if (total >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
     const int64_t grid = std::min<int64_t>(total, (int64_t)st.cus * st.cached_blocks);
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WG), lds, s, a);
     return hipGetLastError();
@@ -341,19 +344,24 @@ bool strip_fits(int kind, int R, int WS)
     return (R / 2 + 2) * (WS / 2 + 2) * (k.ca / 8) <= k.npa * WG && (R + 2) * (WS + 2) * (k.cb / 8) <= k.npb * WG;
 }
 
+#define STRIP_INST(idx, R8, ...)                                                                          \
+    (a.WS == 32 && a.R == R8 ? launch_strip_one(st[SK_COUNT + idx], strip_kernel<__VA_ARGS__, 32, R8>, a, s)   \
+                             : launch_strip_one(st[idx], strip_kernel<__VA_ARGS__, 0, 0>, a, s))
+
 hipError_t launch_strip(int kind, const StripArgs &a, hipStream_t s)
 {
-    static thread_local StripLaunch st[SK_COUNT];
+    static thread_local StripLaunch st[2 * SK_COUNT];
+    // second argument: the band height make_plan picks for 32-column strips (specialised instance)
     switch (kind) {
-    case SK_CONV1: return launch_strip_one(st[0], strip_kernel<32, 0, false, 32, SE_STORE_POOL, false, 3, 1, 3, 6, 0, 2>, a, s);
-    case SK_CONV2: return launch_strip_one(st[1], strip_kernel<32, 0, false, 64, SE_STORE, false, 3, 1, 3, 6, 0, 2>, a, s);
-    case SK_CONV3: return launch_strip_one(st[2], strip_kernel<64, 0, false, 64, SE_STORE_POOL, false, 3, 1, 3, 11, 0, 2>, a, s);
-    case SK_CONV4: return launch_strip_one(st[3], strip_kernel<64, 0, false, 128, SE_STORE, true, 3, 1, 3, 11, 0, 2>, a, s);
-    case SK_CONV5: return launch_strip_one(st[4], strip_kernel<128, 0, false, 128, SE_STORE, false, 3, 1, 3, 11, 0, 2>, a, s);
-    case SK_CONV6: return launch_strip_one(st[5], strip_kernel<128, 64, true, 64, SE_STORE, false, 3, 1, 3, 7, 11, 2>, a, s);
-    case SK_CONV7: return launch_strip_one(st[6], strip_kernel<64, 0, false, 64, SE_STORE, false, 3, 1, 3, 11, 0, 2>, a, s);
-    case SK_CONV8: return launch_strip_one(st[7], strip_kernel<64, 32, true, 32, SE_STORE, false, 3, 1, 3, 4, 6, 2>, a, s);
-    case SK_CONV9: return launch_strip_one(st[8], strip_kernel<32, 0, false, 32, SE_HEAD, false, 3, 1, 3, 6, 0, 2>, a, s);
-    default: return launch_strip_one(st[9], strip_kernel<32, 0, false, 32, SE_STORE, false, 3, 1, 3, 6, 0, 2>, a, s);
+    case SK_CONV1: return STRIP_INST(0, 8, 32, 0, false, 32, SE_STORE_POOL, false, 3, 1, 3, 6, 0, 2);
+    case SK_CONV2: return STRIP_INST(1, 8, 32, 0, false, 64, SE_STORE, false, 3, 1, 3, 6, 0, 2);
+    case SK_CONV3: return STRIP_INST(2, 4, 64, 0, false, 64, SE_STORE_POOL, false, 3, 1, 3, 11, 0, 2);
+    case SK_CONV4: return STRIP_INST(3, 4, 64, 0, false, 128, SE_STORE, true, 3, 1, 3, 11, 0, 2);
+    case SK_CONV5: return STRIP_INST(4, 2, 128, 0, false, 128, SE_STORE, false, 3, 1, 3, 11, 0, 2);
+    case SK_CONV6: return STRIP_INST(5, 4, 128, 64, true, 64, SE_STORE, false, 3, 1, 3, 7, 11, 2);
+    case SK_CONV7: return STRIP_INST(6, 4, 64, 0, false, 64, SE_STORE, false, 3, 1, 3, 11, 0, 2);
+    case SK_CONV8: return STRIP_INST(7, 8, 64, 32, true, 32, SE_STORE, false, 3, 1, 3, 4, 6, 2);
+    case SK_CONV9: return STRIP_INST(8, 8, 32, 0, false, 32, SE_HEAD, false, 3, 1, 3, 6, 0, 2);
+    default: return STRIP_INST(9, 8, 32, 0, false, 32, SE_STORE, false, 3, 1, 3, 6, 0, 2);
     }
 }

@@ -208,11 +208,17 @@ __global__ __launch_bounds__(256) void head_kernel(const InT *__restrict__ a9, i
     const int x = (int)(p % W), y = (int)((p / W) % H);
     const int64_t b = p / ((int64_t)W * H);
     const InT *ip = a9 + ((b * Hp + y) * Wp + x) * F;
-    for (int ch = 0; ch < C; ++ch) {
-        float acc = 0.0f;
-        for (int f = 0; f < F; ++f) acc = __fmaf_rn((float)ip[f], w[f * C + ch], acc);
-        score[p * C + ch] = __fadd_rn(acc, bias[ch]);
+    // 16-byte loads of the pixel's channel vector; the chain still runs over ascending channel index
+    constexpr int V = 16 / sizeof(InT);
+    typedef InT vec_t __attribute__((ext_vector_type(V)));
+    float acc[2] = {0.0f, 0.0f};
+    for (int f0 = 0; f0 < F; f0 += V) {
+        const vec_t v = *(const vec_t *)(ip + f0);
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+            for (int ch = 0; ch < C; ++ch) acc[ch] = __fmaf_rn((float)v[j], w[(f0 + j) * C + ch], acc[ch]);
     }
+    for (int ch = 0; ch < C; ++ch) score[p * C + ch] = __fadd_rn(acc[ch], bias[ch]);
 }
 
 void launch_head(const float *a9, int64_t B, int H, int W, int Hp, int Wp, int F, int C, const float *w,

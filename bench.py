@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel event timing")
     args = ap.parse_args()
 
+    if os.environ.get("ISINGDIFF_BENCH_TRACE"):      # debugging aid: dump every thread's stack after N seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["ISINGDIFF_BENCH_TRACE"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -92,10 +95,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    # one process per GPU; ISINGDIFF_BENCH_BACKEND=gloo lets the N > 1 control flow be rehearsed on a box
+    # with fewer GPUs than ranks (ranks then share devices round-robin; not a measurement)
+    backend = os.environ.get("ISINGDIFF_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from isingdiff import load_model, sample, beta_schedule, allreduce_observables
 
@@ -129,7 +140,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = model.profile_end() if profile else []
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

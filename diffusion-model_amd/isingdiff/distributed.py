@@ -31,5 +31,11 @@ def allreduce_observables(obs: Observables, group=None) -> Observables:
         return obs
     nm, ns = obs.hist_M.numel(), obs.hist_S.numel()
     flat = torch.cat([obs.hist_M, obs.hist_S, obs.moments])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if dist.get_backend(group) == "gloo" and flat.is_cuda:
+        # a host-side group (tests, rehearsals): reduce through host memory
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat = host.to(flat.device)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return Observables(obs.L, obs.M, obs.S, flat[:nm].clone(), flat[nm:nm + ns].clone(), flat[nm + ns:].clone())

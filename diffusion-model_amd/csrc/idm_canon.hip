@@ -13,6 +13,8 @@
 
 #include <math.h>
 
+#include <algorithm>
+
 DEVI float epilogue(float acc, int co, const float *bias, const float *scale, const float *shift, int silu,
                     const float *tadd)
 {
@@ -259,6 +261,35 @@ __global__ __launch_bounds__(256) void update_kernel(float *__restrict__ x, cons
     }
 }
 
+// Same update for elems % 4 == 0 and 16-byte aligned tensors: one float4 per operand per thread.
+__global__ __launch_bounds__(256) void update4_kernel(float *__restrict__ x, const float *__restrict__ score,
+                                                      const float *__restrict__ zin, float c1, float beta, float sd,
+                                                      int64_t n_lattices, int64_t nq, int add_noise, PhiloxArgs ph)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_lattices * nq) return;
+    f32x4 xv = ((const f32x4 *)x)[i];
+    const f32x4 sv = ((const f32x4 *)score)[i];
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (add_noise) {
+        if (zin) {
+            const f32x4 zv = ((const f32x4 *)zin)[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[j] = zv[j];
+        } else {
+            const int64_t b = i / nq;
+            normal4(ph.seed, ph.first_global_index + b, (uint32_t)(i - b * nq), ph.t, z);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = __fadd_rn(__fmul_rn(c1, xv[j]), __fmul_rn(beta, sv[j]));
+        if (add_noise) v = __fadd_rn(v, __fmul_rn(z[j], sd));
+        xv[j] = v;
+    }
+    ((f32x4 *)x)[i] = xv;
+}
+
 void launch_update(float *x, const float *score, const float *z, float beta, int64_t n_lattices, int64_t elems,
                    bool add_noise, const PhiloxArgs &ph, hipStream_t s)
 {
@@ -269,6 +300,12 @@ void launch_update(float *x, const float *score, const float *z, float beta, int
     volatile float half_beta = 0.5f * beta;
     volatile float c1 = 1.0f + half_beta;
     volatile float sd = sqrtf(beta);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(score) | reinterpret_cast<uintptr_t>(z);
+    if ((elems & 3) == 0 && (al & 15) == 0) {
+        hipLaunchKernelGGL(update4_kernel, dim3(grid), dim3(256), 0, s, x, score, z, (float)c1, beta, (float)sd, n_lattices, nq,
+                           add_noise ? 1 : 0, ph);
+        return;
+    }
     hipLaunchKernelGGL(update_kernel, dim3(grid), dim3(256), 0, s, x, score, z, (float)c1, beta, (float)sd, n_lattices,
                        elems, add_noise ? 1 : 0, ph);
 }
@@ -338,8 +375,31 @@ __global__ __launch_bounds__(256) void sign_project_kernel(const float *__restri
     if (i < n) spins[i] = x[i] > 0.0f ? 1 : -1;
 }
 
+// 16 elements per thread: four float4 loads, one 16-byte store.
+__global__ __launch_bounds__(256) void sign_project16_kernel(const float *__restrict__ x, int8_t *__restrict__ spins, int64_t n16)
+{
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    const f32x4 *p = (const f32x4 *)x + i * 4;
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const f32x4 v = p[k];
+        unsigned int w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w |= (v[j] > 0.0f ? 0x01u : 0xffu) << (8 * j);
+        o[k] = w;
+    }
+    ((u32x4 *)spins)[i] = o;
+}
+
 void launch_sign_project(const float *x, int8_t *spins, int64_t n, hipStream_t s)
 {
+    if ((n & 15) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(spins)) & 15) == 0) {
+        hipLaunchKernelGGL(sign_project16_kernel, dim3((unsigned)((n / 16 + 255) / 256)), dim3(256), 0, s, x, spins, n / 16);
+        return;
+    }
     hipLaunchKernelGGL(sign_project_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, spins, n);
 }
 
@@ -386,9 +446,102 @@ __global__ __launch_bounds__(256) void observe_kernel(const int8_t *__restrict__
     }
 }
 
+// Fast path for L % 16 == 0: persistent wavefronts, each lane takes 16 consecutive sites (one 16-byte
+// load) and works on sign bits only: for +-1 spins  sum s = n - 2*popc(negative),  sum s*s' = n - 2*popc(s ^ s').
+// The right neighbour's first byte comes from the neighbouring lane (row wrap: the row's first lane),
+// the row below is a second (cache-resident) load.  Histograms are accumulated in LDS (L <= 64) and
+// moments in registers, flushed once per workgroup.
+__global__ __launch_bounds__(256) void observe_fast_kernel(const int8_t *__restrict__ spins, int64_t B, int L,
+                                                           int32_t *__restrict__ M, int32_t *__restrict__ S,
+                                                           unsigned long long *__restrict__ histM,
+                                                           unsigned long long *__restrict__ histS,
+                                                           long long *__restrict__ moments, int lds_hist)
+{
+    extern __shared__ unsigned int obs_hist[];   // [L*L+1 | 2*L*L+1] when lds_hist
+    __shared__ long long wg_mom[4][6];
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = L * L, nchunk = n >> 4, cpr = L >> 4;   // chunks per lattice / per row
+    const int nbM = n + 1, nbS = 2 * n + 1;
+    if (lds_hist) {
+        for (int i = threadIdx.x; i < nbM + nbS; i += 256) obs_hist[i] = 0u;
+        __syncthreads();
+    }
+    long long mom[6] = {0, 0, 0, 0, 0, 0};
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < B; b += nwaves) {
+        const u32x4 *src = (const u32x4 *)(spins + b * n);
+        int neg = 0, diff = 0;
+        for (int c0 = 0; c0 < nchunk; c0 += 64) {
+            const int c = c0 + lane;
+            const bool act = c < nchunk;
+            const int cc = act ? c : 0;
+            const int down = cc + cpr >= nchunk ? cc + cpr - nchunk : cc + cpr;
+            const u32x4 v = src[cc], d = src[down];
+            // first byte of the next chunk of the same row (wraps to the row's first chunk)
+            const int xin = cc % cpr;
+            const int src_lane = xin + 1 == cpr ? lane - (cpr - 1) : lane + 1;
+            const unsigned int nb = (unsigned int)__shfl((int)v[0], src_lane, 64) & 0xffu;
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned int nxt = j < 3 ? v[j + 1] : nb;
+                    const unsigned int r = (v[j] >> 8) | (nxt << 24);
+                    neg += __popc(v[j] & 0x80808080u);
+                    diff += __popc((v[j] ^ d[j]) & 0x80808080u) + __popc((v[j] ^ r) & 0x80808080u);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            neg += __shfl_down(neg, off, 64);
+            diff += __shfl_down(diff, off, 64);
+        }
+        if (lane == 0) {
+            const int m = n - 2 * neg, bond = 2 * n - 2 * diff;
+            if (M) M[b] = m;
+            if (S) S[b] = bond;
+            if (lds_hist) {
+                atomicAdd(&obs_hist[(m + n) >> 1], 1u);
+                atomicAdd(&obs_hist[nbM + ((bond + 2 * n) >> 1)], 1u);
+            } else {
+                if (histM) atomicAdd(&histM[(m + n) >> 1], 1ull);
+                if (histS) atomicAdd(&histS[(bond + 2 * n) >> 1], 1ull);
+            }
+            mom[0] += 1; mom[1] += m; mom[2] += m < 0 ? -m : m; mom[3] += (long long)m * m;
+            mom[4] += bond; mom[5] += (long long)bond * bond;
+        }
+    }
+    if (lane == 0)
+        for (int k = 0; k < 6; ++k) wg_mom[wave][k] = mom[k];
+    __syncthreads();
+    if (moments && threadIdx.x < 6) {
+        const long long t = wg_mom[0][threadIdx.x] + wg_mom[1][threadIdx.x] + wg_mom[2][threadIdx.x] + wg_mom[3][threadIdx.x];
+        if (t != 0) atomicAdd((unsigned long long *)&moments[threadIdx.x], (unsigned long long)t);
+    }
+    if (lds_hist) {
+        for (int i = threadIdx.x; i < nbM + nbS; i += 256) {
+            const unsigned int v = obs_hist[i];
+            if (v == 0u) continue;
+            if (i < nbM) { if (histM) atomicAdd(&histM[i], (unsigned long long)v); }
+            else if (histS) atomicAdd(&histS[i - nbM], (unsigned long long)v);
+        }
+    }
+}
+
 void launch_observe(const int8_t *spins, int64_t B, int L, int32_t *M, int32_t *S, unsigned long long *histM,
                     unsigned long long *histS, long long *moments, hipStream_t s)
 {
+    // rows must not straddle a wavefront pass of 64 chunks: L/16 a power of two (L = 16, 32, 64, 128, ...)
+    if ((L & 15) == 0 && L <= 1024 && 64 % (L >> 4) == 0 && (reinterpret_cast<uintptr_t>(spins) & 15) == 0) {
+        const int lds_hist = L <= 64 ? 1 : 0;
+        const size_t lds = lds_hist ? (size_t)(3 * L * L + 2) * sizeof(unsigned int) : 0;
+        const int64_t want = (B + 3) / 4;
+        const unsigned grid = (unsigned)std::min<int64_t>(want, 1024);
+        hipLaunchKernelGGL(observe_fast_kernel, dim3(grid), dim3(256), lds, s, spins, B, L, M, S, histM, histS, moments,
+                           lds_hist);
+        return;
+    }
     hipLaunchKernelGGL(observe_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, spins, B, L, M, S, histM, histS,
                        moments);
 }

@@ -90,6 +90,18 @@ int idm_set_error(int code, const char *msg) { return fail(code, msg ? msg : "")
 
 std::vector<float> idm_pack_weights_f32(const float *w, int cin, int cout) { return pack_weights_f32(w, cin, cout); }
 
+std::vector<float> idm_pack_weights_f32_1x1(const float *w, int cin, int cout)
+{
+    const int ncg = cin / 8, mt = cout / 32;
+    std::vector<float> p((size_t)cin * cout);
+    size_t o = 0;
+    for (int cg = 0; cg < ncg; ++cg)
+        for (int m = 0; m < mt; ++m)
+            for (int l = 0; l < 64; ++l)
+                for (int s = 0; s < 4; ++s) p[o++] = w[(size_t)(cg * 8 + 2 * s + (l >> 5)) * cout + m * 32 + (l & 31)];
+    return p;
+}
+
 struct idm_model {
     int device = 0;
     int C = 1, F = 32;

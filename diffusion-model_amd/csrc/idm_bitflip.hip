@@ -217,7 +217,7 @@ inline unsigned blocks(int64_t n) { return (unsigned)((n + 255) / 256); }
 struct idm_bitflip {
     int device = 0;
     const float *t[IDM_BITFLIP_NTENSOR] = {};   // device copies, Keras layouts
-    void *c1_pack[NBLK] = {}, *c2_pack[NBLK] = {};
+    void *c1_pack[NBLK] = {}, *c2_pack[NBLK] = {}, *s_pack[NBLK] = {};
     float *emb_dev = nullptr;   // (T, EMB) scratch for the embedding rows
     int emb_cap = 0;
     float *tvec = nullptr;      // (T, TVEC)
@@ -332,8 +332,18 @@ void resblock(idm_bitflip *m, int i, const float *x, int64_t B, int H, int W, co
     gn_silu(tbuf, B, HW, Cw, m->t[tb(i, K_G2_G)], m->t[tb(i, K_G2_B)], ab, ta, s);
     conv3(ta, B, H, W, Cw, m->c2_pack[i], m->t[tb(i, K_C2_B)], nullptr, tbuf, Cw, s);
     const int64_t npix = B * HW;
-    hipLaunchKernelGGL(bf_shortcut_kernel, dim3(blocks(npix * Cw)), dim3(256), 0, s, x, Cin, m->t[tb(i, K_S_W)],
-                       m->t[tb(i, K_S_B)], (const float *)tbuf, out, npix, Cw);
+    if (m->s_pack[i]) {
+        // projected shortcut (:188-192) on the matrix cores: the centre tap alone is a 1x1 convolution with the
+        // same k-ordered chain; out = (chain + bias) + h
+        ConvArgs a = {};
+        a.in0 = x; a.C0 = Cin; a.C1 = 0; a.H = H; a.W = W; a.B = B; a.wpack = m->s_pack[i]; a.bias = m->t[tb(i, K_S_B)];
+        a.out = out; a.Cout = Cw; a.mode = CONV_PLAIN; a.silu = 0; a.out_f32 = 1;
+        a.tap_lo = 4; a.tap_hi = 5; a.resid = tbuf;
+        launch_conv_f32(a, s);
+    } else {
+        hipLaunchKernelGGL(bf_shortcut_kernel, dim3(blocks(npix * Cw)), dim3(256), 0, s, x, Cin, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)tbuf, out, npix, Cw);
+    }
 }
 
 // Forward of Bc samples; tvec: this step's five time vectors (device); proba (Bc,H,W).
@@ -421,6 +431,12 @@ int idm_bitflip_create(idm_bitflip **out, int device, const idm_bitflip_desc *d)
             float *pd = nullptr;
             rc = bf_upload(m, pk.data(), pk.size(), &pd);
             (k == K_C1_W ? m->c1_pack : m->c2_pack)[blk] = pd;
+        }
+        if (rc == IDM_OK && in_blk && k == K_S_W) {
+            std::vector<float> pk = idm_pack_weights_f32_1x1(d->tensors[i], kCin[blk], kWidth[blk]);
+            float *pd = nullptr;
+            rc = bf_upload(m, pk.data(), pk.size(), &pd);
+            m->s_pack[blk] = pd;
         }
     }
     if (rc != IDM_OK) {

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
 
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = a.tap_lo; tap < a.tap_hi; ++tap) {
         const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
         const bool inb = pv && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
         for (int cg = 0; cg < ncg; ++cg) {
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a)
                     for (int j = 0; j < 4; ++j) { v[j] = q0[j]; v[4 + j] = q1[j]; }
                 }
             }
-            const f32x4 *w = wp + (int64_t)(tap * ncg + cg) * MT * 64;
+            const f32x4 *w = wp + (int64_t)((tap - a.tap_lo) * ncg + cg) * MT * 64;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const f32x4 wv = w[m * 64];
@@ -114,7 +114,9 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(ConvArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            out[co] = epilogue(acc[m][r], co, a.bias, a.scale, a.shift, a.silu, a.tadd);
+            float z = epilogue(acc[m][r], co, a.bias, a.scale, a.shift, a.silu, a.tadd);
+            if (a.resid) z = __fadd_rn(z, a.resid[p * a.Cout + co]);
+            out[co] = z;
         }
 }
 

@@ -10,6 +10,8 @@
 int idm_set_error(int code, const char *msg);
 // Keras kernel (3,3,Cin,Cout) -> float A operands of v_mfma_f32_32x32x2_f32, [tap][c/8][mt][lane][4].
 std::vector<float> idm_pack_weights_f32(const float *w, int cin, int cout);
+// the same for a (Cin,Cout) 1x1 kernel: one tap
+std::vector<float> idm_pack_weights_f32_1x1(const float *w, int cin, int cout);
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -41,6 +43,10 @@ struct ConvArgs {
     int mode;
     int silu;
     int out_f32;         // bf16 pipeline only: store float32 instead of bf16
+    // float32 kernel only: taps [tap_lo, tap_hi) of the 3x3 stencil are evaluated and wpack holds exactly those
+    // (tap_lo = 4, tap_hi = 5 with a one-tap pack is a 1x1 convolution); resid (same shape as out) is added last
+    int tap_lo = 0, tap_hi = 9;
+    const float *resid = nullptr;
 };
 
 struct PhiloxArgs {

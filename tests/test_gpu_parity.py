@@ -132,7 +132,7 @@ def test_bf16_strip_kernels_match_fused_and_per_layer(gpu_real, B, L, t):
 
 @pytest.mark.parametrize("L", [64, 128])
 def test_large_lattices(gpu_real, real_spec, ref_real, L):
-    """The L=20-trained weights applied convolutionally at L=64 / 128 (BASELINE config 3):
+    """The L=20-trained weights applied convolutionally at L=64 / 128 (the large-lattice configuration):
     fp32 bit-exact, bf16 within tolerance."""
     from oracle import ref_cpu
     rng = np.random.default_rng(L)

@@ -63,9 +63,16 @@ DEVI bf16x8 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
 }
 
 // Per-lane geometry of the 32-pixel MFMA tiles of a map of width W, fixed for a kernel launch.
-// W <= 32: a tile is TR = 32 / W row slots of W pixels; lane li sits in slot li / W, column li % W,
-// and slot s of tile j is row j + s * Rh of the stage's output region (Rh = ceil(rows / TR)), so
-// that vertically adjacent tiles j, j+1, ... touch input rows that differ by exactly one.
+// W <= 32: a tile is TR = 32 / W row slots of W pixels, and slot s of tile j is row j + s * Rh of the
+// stage's output region (Rh = ceil(rows / TR)), so that vertically adjacent tiles j, j+1, ... touch
+// input rows that differ by exactly one.  Which lane holds which pixel of the tile is free (the MFMA
+// only sees 32 columns), and it decides the LDS bank conflicts of the operand reads: a ds_read_b128 is
+// served in the 16-lane groups {0-3,12-15,20-27} and {4-11,16-19,28-31} (per half wave), i.e. by the
+// parity of li >> 2, and a group is conflict-free when it reads 16 different columns of ONE row (the
+// pixel stride is an odd number of 16-byte units).  W = 16 therefore puts one slot in each group.
+// W = 8 puts slots {0,2} in one group and {1,3} in the other: two 8-column rows share a group without
+// conflicts when they lie 128 bytes (mod 256) apart, which 2 * Rh row pitches are for Rh = 2, the
+// whole-map 8x8 case.  Other widths: slot li / W, column li % W.
 // W > 32: a tile is 32 consecutive columns of one row (ncb column blocks).
 struct LaneGeo {
     int W, ncb, TR, slot, col;
@@ -79,8 +86,17 @@ DEVI LaneGeo make_geo(int W, int li)
     g.ncb = (W + 31) >> 5;
     if (g.ncb == 1) {
         g.TR = 32 / W;
-        g.slot = li / W;
-        g.col = li - g.slot * W;
+        const int par = ((li >> 2) ^ (li >> 3) ^ (li >> 4)) & 1;
+        if (W == 16) {
+            g.slot = par;
+            g.col = ((li >> 1) & 12) | (li & 3);
+        } else if (W == 8) {
+            g.slot = par + 2 * (li >> 4);
+            g.col = ((li >> 1) & 4) | (li & 3);
+        } else {
+            g.slot = li / W;
+            g.col = li - g.slot * W;
+        }
         g.ok = g.slot < g.TR;
         if (!g.ok) g.slot = 0;
     } else {

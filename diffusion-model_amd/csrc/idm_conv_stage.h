@@ -182,9 +182,20 @@ struct ConvStage {
         f = (wave * tot) >> 2;
         f1 = ((wave + 1) * tot) >> 2;
         if (f < f1) {
-            set_slice((f / Rh) % NSL);
+            set_slice(unit_of(f) % NSL);
             prologue();
         }
+    }
+
+    // f / Rh.  With one column block there are only NSL units, and a few compares replace the
+    // division (a float-reciprocal sequence of ~20 vector instructions on this target).
+    DEVI int unit_of(int ff) const
+    {
+        if (g.ncb != 1) return ff / Rh;
+        int u = 0;
+#pragma unroll
+        for (int k = 1; k < NSL; ++k) u += ff >= k * Rh;
+        return u;
     }
 
     template <int N, class Epi>
@@ -279,9 +290,13 @@ struct ConvStage {
         bool fetched = true;
 #pragma unroll 1
         while (f < f1) {
-            const int u = f / Rh, j = f - u * Rh;
+            const int u = unit_of(f), j = f - u * Rh;
             const int len = min(f1 - f, Rh - j);
-            const int np = (len + NT - 1) / NT, cnt = (len + np - 1) / np;
+            // np pieces of at most NT tiles, as even as possible: cnt = ceil(len / np) <= NT
+            const int np = (len + NT - 1) / NT;
+            int cnt = 1;
+#pragma unroll
+            for (int k = 1; k < NT; ++k) cnt += k * np < len;
             const int sl = u % NSL, cb = u / NSL;
             if (!fetched) {
                 set_slice(sl);

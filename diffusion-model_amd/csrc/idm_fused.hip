@@ -74,7 +74,7 @@ DEVI void conv_first_stage(const float *xs, const float *c0, int W, int r0, int 
 // Register-held payload of one LDS input tile: NP 16-byte items per thread (item i = tid + k*WG
 // covers row i / (W*C/8), 8 channels).  load() reads rows [g0, g0+nrows) of a global NHWC bf16 map
 // (zeros outside [0,Hmap)); store() writes them into the tile (row t = global row g0+t) and clears
-// the tile's two halo columns.  Splitting the two lets the loads of the next band fly while the
+// (unless HALO is false) the tile's two halo columns.  Splitting the two lets the loads of the next band fly while the
 // current band is still being computed.
 template <int C, int NP>
 struct TileRegs {
@@ -99,6 +99,7 @@ struct TileRegs {
         }
     }
 
+    template <bool HALO = true>
     DEVI void store(char *tile, int W, int nrows, int tid) const
     {
         const int ipr = W * CH;
@@ -111,12 +112,14 @@ struct TileRegs {
             row += drow;
             if (rem >= ipr) { rem -= ipr; ++row; }
         }
-        bf16x8 z;
+        if constexpr (HALO) {
+            bf16x8 z;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f;
-        for (int i = tid; i < nrows * 2 * CH; i += WG) {
-            const int ch = i % CH, side = (i / CH) & 1, r = i / (2 * CH);
-            *(bf16x8 *)(tile + (r * (W + 2) + side * (W + 1)) * S + ch * 16) = z;
+            for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f;
+            for (int i = tid; i < nrows * 2 * CH; i += WG) {
+                const int ch = i % CH, side = (i / CH) & 1, r = i / (2 * CH);
+                *(bf16x8 *)(tile + (r * (W + 2) + side * (W + 1)) * S + ch * 16) = z;
+            }
         }
     }
 };
@@ -195,14 +198,17 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
     int tl_it = 0;
 #endif
 
-    // LDS map: [input region | mid tile | epilogue constants]; the output staging / score buffer
-    // reuses the input region.
+    // LDS map: [input region | mid tile | epilogue constants | score tile (HEAD)]; the output staging
+    // buffer reuses the input region.  HEAD keeps its score tile apart, so nothing but the tile copies
+    // ever writes the input tiles: their halo columns are cleared once, and the band loop needs no
+    // barrier between the state update and the next band's copy-in.
     char *lds_in = smem;
     char *lds_mid = smem + a.lds_in_bytes;
     char *tile_a = lds_in;
     char *tile_b = MODE1 == M1_UPCAT ? lds_in + ((((R >> 1) + 2) * ((W >> 1) + 2) * SA + 15) & ~15) : nullptr;
     constexpr int NCONST = 2 * C1 + 2 * C2 + 4;
-    float *cst = (float *)(smem + a.lds_in_bytes + a.lds_mid_bytes) - NCONST;
+    float *score_s = (float *)(smem + a.lds_in_bytes + a.lds_mid_bytes - (EPI2 == E2_HEAD ? (R * W * 4 + 15) & ~15 : 0));
+    float *cst = score_s - NCONST;
     const float *c_b1 = cst, *c_t1 = cst + C1, *c_b2 = cst + 2 * C1, *c_wh = c_b2 + C2, *c_bh = c_b2 + 2 * C2;
     (void)c_t1; (void)c_wh; (void)c_bh;
     for (int i = tid; i < C1; i += WG) {
@@ -263,8 +269,8 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
         } else if constexpr (MODE1 == M1_PLAIN) {
             ra.store(tile_a, W, R + 4, tid);
         } else {
-            ra.store(tile_a, W >> 1, (R >> 1) + 2, tid);
-            rb.store(tile_b, W, R + 4, tid);
+            ra.template store<EPI2 != E2_HEAD>(tile_a, W >> 1, (R >> 1) + 2, tid);
+            rb.template store<EPI2 != E2_HEAD>(tile_b, W, R + 4, tid);
         }
     };
 
@@ -294,7 +300,8 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
             nl += light;
         }
         const int rowsx = min(min(R, H - y0), Hx - y0);
-        const int qrow = Wx >> 2, nq = max(rowsx, 0) * qrow, qpw = (nq + nl - 1) / nl;
+        const int qrow = Wx >> 2, nq = max(rowsx, 0) * qrow;
+        const int qpw = nl == 4 ? (nq + 3) >> 2 : nl == 2 ? (nq + 1) >> 1 : nl == 1 ? nq : (nq + 2) / 3;
         q.path = WT ? true : ((Wx & 3) == 0 && qpw <= 64);
         const int qi = lr * qpw + lane;
         q.act = q.path && mine && lane < qpw && qi < nq;
@@ -323,6 +330,10 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
     };
 
     clear_halo<C1>(lds_mid, W, R + 2, 0, 0, tid);  // halo columns of the mid tile: never written afterwards
+    if constexpr (EPI2 == E2_HEAD && MODE1 == M1_UPCAT) {
+        clear_halo<CA>(tile_a, W >> 1, (R >> 1) + 2, 0, 0, tid);
+        clear_halo<CB>(tile_b, W, R + 4, 0, 0, tid);
+    }
     int wg = blockIdx.x;
     Item cur = item_of(wg < total ? wg : 0);
     if (wg < total) {
@@ -392,7 +403,6 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
         __syncthreads();
         TL(4);
         if constexpr (EPI2 == E2_HEAD) {
-            float *score_s = (float *)lds_in;  // rows2 * W floats
             auto epi2 = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *kw, int mt, int r, int x, bool valid) {
                 (void)mt;
                 f32x4 p4 = {0.f, 0.f, 0.f, 0.f};
@@ -503,7 +513,7 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
             }
         }
         TL(7);
-        __syncthreads();  // staging / score consumed before the next band's input overwrites the region
+        if constexpr (EPI2 != E2_HEAD) __syncthreads();  // staging consumed before the next band's input overwrites the region
         TL(8);
         cur = nxt;
 #ifdef IDM_TIMELINE
@@ -549,10 +559,10 @@ void fused_lds_bytes(int kind, int W, int R, int *in_bytes, int *mid_bytes)
     if (k.mode1 == M1_FIRST) in = (R + 4) * (W + 2) * 4;
     else if (k.mode1 == M1_PLAIN) in = (R + 4) * (W + 2) * sa;
     else in = align16((R / 2 + 2) * (W / 2 + 2) * sa) + (R + 4) * (W + 2) * sb;
-    const int stage = k.epi2 == E2_HEAD ? R * W * 4 : R * W * so;
+    const int stage = k.epi2 == E2_HEAD ? 0 : R * W * so;
     *in_bytes = align16(in > stage ? in : stage);
-    // mid tile, then the epilogue constants (2*C1 + 2*C2 + 4 floats)
-    *mid_bytes = align16((R + 2) * (W + 2) * sm) + (2 * k.c1 + 2 * k.c2 + 4) * 4;
+    // mid tile, then the epilogue constants (2*C1 + 2*C2 + 4 floats), then HEAD's score tile
+    *mid_bytes = align16((R + 2) * (W + 2) * sm) + (2 * k.c1 + 2 * k.c2 + 4) * 4 + (k.epi2 == E2_HEAD ? align16(R * W * 4) : 0);
 }
 
 // Launch state per kernel instance (all instances share one function-pointer type, so the

@@ -89,6 +89,13 @@ struct TileRegs {
         const int ipr = W * CH;
         int row = tid / ipr, rem = tid - row * ipr;
         const int drow = WG / ipr, drem = WG - drow * ipr;
+        if (drem == 0) {  // a thread's items share one tile column: rows step by drow, offsets by a constant
+            const int off0 = ((g0 + row) * ipr + rem) * 16;
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+                v[k] = buf_load16(rs, row + k * drow < nrows ? (unsigned)(off0 + k * drow * ipr * 16) : 0x80000000u, 0);
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             const int off = ((g0 + row) * ipr + rem) * 16;
@@ -105,12 +112,19 @@ struct TileRegs {
         const int ipr = W * CH;
         int row = tid / ipr, rem = tid - row * ipr;
         const int drow = WG / ipr, drem = WG - drow * ipr;
+        if (drem == 0) {
+            char *p0 = tile + (row * (W + 2) + rem / CH + 1) * S + (rem % CH) * 16;
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            if (row < nrows) *(bf16x8 *)(tile + (row * (W + 2) + rem / CH + 1) * S + (rem % CH) * 16) = v[k];
-            rem += drem;
-            row += drow;
-            if (rem >= ipr) { rem -= ipr; ++row; }
+            for (int k = 0; k < NP; ++k)
+                if (row + k * drow < nrows) *(bf16x8 *)(p0 + k * drow * (W + 2) * S) = v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if (row < nrows) *(bf16x8 *)(tile + (row * (W + 2) + rem / CH + 1) * S + (rem % CH) * 16) = v[k];
+                rem += drem;
+                row += drow;
+                if (rem >= ipr) { rem -= ipr; ++row; }
+            }
         }
         if constexpr (HALO) {
             bf16x8 z;
@@ -239,6 +253,7 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
     auto pf_load = [&](Item it) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
+        __builtin_assume(tid >= 0 && tid < WG);
         const int b = it.b, y0 = it.y0;
         if constexpr (MODE1 == M1_FIRST) {
             const float *x = (const float *)a.in_a + (size_t)b * Hx * Wx;
@@ -258,6 +273,7 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
     auto pf_store = [&]() {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
+        __builtin_assume(tid >= 0 && tid < WG);
         if constexpr (MODE1 == M1_FIRST) {
             float *xs = (float *)lds_in;
 #pragma unroll
@@ -383,7 +399,11 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
                 const Quad q = quad_of(cur);
                 if (q.act) {
                     const int64_t lat = (int64_t)b * Hx * Wx;
-                    normal4(a.ph.seed, a.ph.first_global_index + b, (uint32_t)((q.off - lat) >> 2), a.ph.t, zq);
+                    // (the key halves are made opaque per band: otherwise the ten round keys are kept in
+                    // scalar registers across the whole loop, which spills other scalars into vector lanes)
+                    uint32_t k0 = (uint32_t)a.ph.seed, k1 = (uint32_t)(a.ph.seed >> 32);
+                    asm volatile("" : "+s"(k0), "+s"(k1));
+                    normal4(((uint64_t)k1 << 32) | k0, a.ph.first_global_index + b, (uint32_t)((q.off - lat) >> 2), a.ph.t, zq);
                 }
             }
         }

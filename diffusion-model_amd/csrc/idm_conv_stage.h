@@ -160,7 +160,12 @@ struct ConvStage {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int m = 0; m < MS; ++m) wreg[S % WR][ky][m] = buf_load16(wrsrc, woff, (((ky * 3 + kx) * NCG + cg) * MTOT + m) * 1024);
+            for (int m = 0; m < MS; ++m) {
+                // the low 12 bits of the constant ride in the instruction's immediate offset, so the
+                // fetches of a stage share a few scalar 4 KB bases instead of one scalar constant each
+                const unsigned k = (((ky * 3 + kx) * NCG + cg) * MTOT + m) * 1024;
+                wreg[S % WR][ky][m] = buf_load16(wrsrc, woff + (k & 0xFFFu), k & ~0xFFFu);
+            }
     }
 
     DEVI void prologue()
@@ -204,14 +209,27 @@ struct ConvStage {
         const int W = g.W, Wp2 = W + 2, Wh2 = (W >> 1) + 2;
         const int cc = cb * 32 + g.col;
         const int ca = min(cc, W - 1);
-        const int rbase = r0 + j + g.slot * Rh, rmax = r0 + nrows + 1;
+        const int rbase = r0 + j + __mul24(g.slot, Rh), rmax = r0 + nrows + 1;
+        // Fragment i of the piece reads input row min(rbase + i, rmax).  One 24-bit multiply per tile
+        // gives the first row's address; the others follow by constant steps, clamped to the last row's.
         int a_pl[N + 2], a_up[N + 2], a_b[N + 2], c_up[3];
+        if constexpr (UP) {
+            const int PU = Wh2 * SA, t = rbase + up_rb;
+            const int first = __mul24(t >> 1, PU), last = __mul24((rmax + up_rb) >> 1, PU);
+            const int odd = (t & 1) ? PU : 0;   // half-resolution row of fragment i: (t >> 1) + ((t & 1) + i >> 1)
 #pragma unroll
-        for (int i = 0; i < N + 2; ++i) {
-            const int r = min(rbase + i, rmax);
-            if constexpr (UP) a_up[i] = ((r + up_rb) >> 1) * (Wh2 * SA);
-            else a_pl[i] = (r * Wp2 + ca) * SA + h * 16;
-            a_b[i] = (r * Wp2 + ca) * SB + h * 16;
+            for (int i = 0; i < N + 2; ++i) a_up[i] = min(first + (i >> 1) * PU + ((i & 1) ? odd : 0), last);
+        } else {
+            const int PA = Wp2 * SA, col = ca * SA + h * 16;
+            const int first = __mul24(rbase, PA) + col, last = __mul24(rmax, PA) + col;
+#pragma unroll
+            for (int i = 0; i < N + 2; ++i) a_pl[i] = min(first + i * PA, last);
+        }
+        if constexpr (CB > 0) {
+            const int PB = Wp2 * SB, col = ca * SB + h * 16;
+            const int first = __mul24(rbase, PB) + col, last = __mul24(rmax, PB) + col;
+#pragma unroll
+            for (int i = 0; i < N + 2; ++i) a_b[i] = min(first + i * PB, last);
         }
         if constexpr (UP) {
 #pragma unroll

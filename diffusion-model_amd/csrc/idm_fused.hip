@@ -379,7 +379,7 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
         {
             auto epi1 = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *kt, int mt, int r, int x, bool valid) {
                 if (!valid) return;
-                char *dst = lds_mid + (r * (W + 2) + x + 1) * SM + (mt * 32 + 4 * h) * 2;
+                char *dst = lds_mid + __mul24(__mul24(r, W + 2) + x + 1, SM) + (mt * 32 + 4 * h) * 2;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
             char *stage = lds_in;  // [rows2][W] positions of SO bytes
             auto epi2 = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *, int mt, int r, int x, bool valid) {
                 if (!valid) return;
-                char *dst = stage + (r * W + x) * SO + (mt * 32 + 4 * h) * 2;
+                char *dst = stage + __mul24(__mul24(r, W) + x, SO) + (mt * 32 + 4 * h) * 2;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};

@@ -624,16 +624,16 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
 #define IDM_CFG_A 1, 1, 3, 2, 1, 6, 3, 0, 3
 #endif
 #ifndef IDM_CFG_M1
-#define IDM_CFG_M1 3, 1, 3, 2, 1, 3, 5, 0, 2
+#define IDM_CFG_M1 3, 1, 1, 2, 1, 1, 5, 0, 2
 #endif
 #ifndef IDM_CFG_M2
-#define IDM_CFG_M2 2, 1, 3, 2, 1, 3, 3, 0, 2
+#define IDM_CFG_M2 2, 1, 2, 2, 1, 2, 3, 0, 2
 #endif
 #ifndef IDM_CFG_M3
-#define IDM_CFG_M3 3, 1, 3, 2, 1, 3, 3, 6, 2
+#define IDM_CFG_M3 3, 1, 2, 2, 1, 3, 3, 6, 2
 #endif
 #ifndef IDM_CFG_B
-#define IDM_CFG_B 3, 1, 3, 2, 1, 3, 3, 6, 2
+#define IDM_CFG_B 3, 1, 2, 2, 1, 3, 3, 6, 2
 #endif
 
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)

@@ -554,7 +554,7 @@ constexpr KindInfo kKinds[5] = {
     {M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, 3, 0},    // FK_A : x -> conv0 -> conv1 -> skip1, pooled
     {M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, 5, 0},   // FK_M1: pooled -> conv2 -> conv3 -> skip2, pooled
     {M1_PLAIN, 64, 0, 128, 128, E2_STORE, 3, 0},      // FK_M2: pooled -> conv4 (+time) -> conv5
-    {M1_UPCAT, 128, 64, 64, 64, E2_STORE, 3, 6},      // FK_M3: [up(conv5), skip2] -> conv6 -> conv7
+    {M1_UPCAT, 128, 64, 64, 64, E2_STORE, 5, 10},     // FK_M3: [up(conv5), skip2] -> conv6 -> conv7 (whole 16x16 map)
     {M1_UPCAT, 64, 32, 32, 32, E2_HEAD, 3, 6},        // FK_B : [up(conv7), skip1] -> conv8 -> conv9 -> head -> update
 };
 
@@ -630,7 +630,7 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
 #define IDM_CFG_M2 2, 1, 2, 2, 1, 2, 3, 0, 2
 #endif
 #ifndef IDM_CFG_M3
-#define IDM_CFG_M3 3, 1, 2, 2, 1, 3, 3, 6, 2
+#define IDM_CFG_M3 4, 1, 2, 4, 1, 3, 5, 10, 1
 #endif
 #ifndef IDM_CFG_B
 #define IDM_CFG_B 3, 1, 2, 2, 1, 3, 3, 6, 2
@@ -639,15 +639,15 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
 {
     static thread_local LaunchState st[10];
-    // instances specialised for the L = 32 pyramid (widths 32 / 16 / 8, 8-row bands, no padding)
-    const int w32[5] = {32, 16, 8, 16, 32};
-    const bool spec = a.W == w32[kind] && a.R == 8 && a.Hx == 32 && a.Wx == 32;
+    // instances specialised for the L = 32 pyramid (widths 32 / 16 / 8; 8-row bands, M3 the whole 16-row map; no padding)
+    const int w32[5] = {32, 16, 8, 16, 32}, r32[5] = {8, 8, 8, 16, 8};
+    const bool spec = a.W == w32[kind] && a.R == r32[kind] && a.Hx == 32 && a.Wx == 32;
     if (spec) {
         switch (kind) {
         case FK_A: return launch_one(st[5], fused2_kernel<M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, false, IDM_CFG_A, 32, 8>, a, B, s);
         case FK_M1: return launch_one(st[6], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1, 16, 8>, a, B, s);
         case FK_M2: return launch_one(st[7], fused2_kernel<M1_PLAIN, 64, 0, 128, 128, E2_STORE, true, IDM_CFG_M2, 8, 8>, a, B, s);
-        case FK_M3: return launch_one(st[8], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, IDM_CFG_M3, 16, 8>, a, B, s);
+        case FK_M3: return launch_one(st[8], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, IDM_CFG_M3, 16, 16>, a, B, s);
         default: return launch_one(st[9], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, IDM_CFG_B, 32, 8>, a, B, s);
         }
     }

@@ -1,6 +1,5 @@
 #!/bin/bash
-# Experiment: fused kernels with whole-map / 16-row bands at one workgroup per CU (library built with taller
-# prefetch registers) against the 8-row bands at two workgroups per CU.
+# Experiment: fused_B with 16-row bands at one workgroup per CU (libraries built with -DIDM_EXP_B16).
 mkdir -p gpurun_out
 run() { timeout -k 10 200 python -u bench.py --batch 4096 --T 50 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/tb.json 2> gpurun_out/tb.err || { tail -5 gpurun_out/tb.err; exit 1; }
   python - "$1" <<'PY'
@@ -10,9 +9,7 @@ print(f"{sys.argv[1]:22s} {d['value']:9.1f} E={d['observables']['mean_E_per_site
 PY
 }
 export ISINGDIFF_LIB=$PWD/diffusion-model_amd/isingdiff/libisingdiff.so; run base
-export ISINGDIFF_LIB=$PWD/diffusion-model_amd/isingdiff/abl/lib_tall.so
-run tall_lib_8row
-export IDM_EXP_BAND_LIMIT_KB=159
-for k in 8 16 24; do export IDM_EXP_BAND_KINDS=$k; run tall_kinds_$k; done
-unset IDM_EXP_BAND_LIMIT_KB IDM_EXP_BAND_KINDS
+export IDM_EXP_B_ROWS=16
+for v in b16a b16b b16c b16d; do export ISINGDIFF_LIB=$PWD/diffusion-model_amd/isingdiff/abl/lib_$v.so; run $v; done
+unset IDM_EXP_B_ROWS
 export ISINGDIFF_LIB=$PWD/diffusion-model_amd/isingdiff/libisingdiff.so; run base

@@ -620,11 +620,13 @@ hipError_t launch_irfft2_sign(const float *spec, int64_t B, int L, int8_t *spins
 {
     const int K = L / 2 + 1;
     const size_t lds = (size_t)(2 * L + 4 * L * K) * sizeof(double);
-    static thread_local bool configured = false;
-    if (!configured) {
+    static thread_local bool configured[IDM_MAX_DEVICES] = {};
+    const int slot = idm_device_slot();
+    if (slot < 0) return hipErrorInvalidDevice;
+    if (!configured[slot]) {
         hipError_t e = hipFuncSetAttribute((const void *)irfft2_sign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        configured = true;
+        configured[slot] = true;
     }
     hipLaunchKernelGGL(irfft2_sign_kernel, dim3((unsigned)B), dim3(256), lds, s, spec, L, spins, real_out);
     return hipGetLastError();

@@ -638,7 +638,10 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
 
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
 {
-    static thread_local LaunchState st[10];
+    static thread_local LaunchState all_st[IDM_MAX_DEVICES][10];
+    const int slot = idm_device_slot();
+    if (slot < 0) return hipErrorInvalidDevice;
+    LaunchState *st = all_st[slot];
     // instances specialised for the L = 32 pyramid (widths 32 / 16 / 8; 8-row bands, M3 the whole 16-row map; no padding)
     const int w32[5] = {32, 16, 8, 16, 32}, r32[5] = {8, 8, 8, 16, 8};
     const bool spec = a.W == w32[kind] && a.R == r32[kind] && a.Hx == 32 && a.Wx == 32;

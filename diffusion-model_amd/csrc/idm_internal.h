@@ -144,3 +144,13 @@ struct StripArgs {
 void strip_lds_bytes(int kind, int R, int WS, int *in_bytes, int *stage_bytes, int *const_bytes);
 bool strip_fits(int kind, int R, int WS);
 hipError_t launch_strip(int kind, const StripArgs &a, hipStream_t s);
+
+// Per-kernel launch state (function attributes, occupancy) is set per device: the caches are indexed by the
+// current device of the calling thread.  Returns -1 (and the launchers fail) beyond IDM_MAX_DEVICES.
+constexpr int IDM_MAX_DEVICES = 64;
+inline int idm_device_slot()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= IDM_MAX_DEVICES) return -1;
+    return d;
+}

@@ -350,7 +350,10 @@ bool strip_fits(int kind, int R, int WS)
 
 hipError_t launch_strip(int kind, const StripArgs &a, hipStream_t s)
 {
-    static thread_local StripLaunch st[2 * SK_COUNT];
+    static thread_local StripLaunch all_st[IDM_MAX_DEVICES][2 * SK_COUNT];
+    const int slot = idm_device_slot();
+    if (slot < 0) return hipErrorInvalidDevice;
+    StripLaunch *st = all_st[slot];
     // second argument: the band height make_plan picks for 32-column strips (specialised instance)
     switch (kind) {
     case SK_CONV1: return STRIP_INST(0, 8, 32, 0, false, 32, SE_STORE_POOL, false, 3, 1, 3, 6, 0, 2);

@@ -18,7 +18,10 @@
  *   - Tensors are dense, NHWC, little-endian: state and score are float32 (B,H,W,C).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls enqueue work
  *     on that stream and return without synchronising unless stated otherwise.
- *   - A model handle is bound to one device and is not thread-safe; distinct handles are.
+ *   - A model handle is bound to one device and is not thread-safe; distinct handles are.  The calls
+ *     on one handle share its activation workspace, so work enqueued through one handle must be
+ *     ordered (one stream, or streams the caller synchronises); a call that has to grow the
+ *     workspace synchronises the device first.
  */
 #ifndef ISINGDIFF_H
 #define ISINGDIFF_H

@@ -168,16 +168,11 @@ struct StepCtx {
     PhiloxArgs ph = {0, 0, 0};
 };
 
-// Largest band height whose LDS footprint leaves room for two workgroups per CU (FK_M3: see below).
+// Largest band height whose LDS footprint leaves room for two workgroups per CU.
 int pick_band_rows(int kind, int H, int W)
 {
     const int limit = 78 * 1024;
-    // conv6 + conv7 (wide K, 25 % halo recompute at 8 rows): the whole map in one workgroup per CU wins when it fits
-    if (kind == FK_M3) {
-        int in = 0, mid = 0;
-        fused_lds_bytes(kind, W, H, &in, &mid);
-        if (!(H & 1) && in + mid <= 159 * 1024 && fused_band_fits(kind, W, H)) return H;
-    }
+    if (const int tall = fused_tall_rows(kind, H, W)) return tall;   // kinds that run one workgroup per CU
     const int cand[5] = {H, 16, 8, 4, 2};
     for (int i = 0; i < 5; ++i) {
         const int R = cand[i];

@@ -110,8 +110,8 @@ DEVI LaneGeo make_geo(int W, int li)
 
 // One 3x3 convolution stage over `nrows` output rows of an LDS-resident input tile.
 //
-// Work is cut into (cout slice, column block, row j) items and split evenly over the four
-// wavefronts; a wavefront processes up to NT vertically adjacent tiles at once.  Because tile n's
+// Work is cut into (cout slice, column block, row j) items and split evenly over the workgroup's
+// wavefronts (four unless begin() is told otherwise); a wavefront processes up to NT vertically adjacent tiles at once.  Because tile n's
 // operand for tap row ky is input row j + n + ky, the NT + 2 activation fragments of one
 // (kx, channel group) "superstep" feed all 3 * NT MFMAs of that superstep: LDS traffic drops from
 // one 1 KB read per MFMA to (NT + 2) / (3 * NT * MS).  Supersteps are fully unrolled (static
@@ -176,7 +176,7 @@ struct ConvStage {
     // up_row_bias: parity of the global row of window row 0 (UP part): the half-resolution window row of
     // full-resolution window row r is (r + up_row_bias) >> 1.
     DEVI void begin(const char *la, const char *lb, const float *c0_, const float *c1_, const LaneGeo &geo, int r0_,
-                    int nrows_, const bf16x8 *w, int wave, int lane, int up_row_bias = 0)
+                    int nrows_, const bf16x8 *w, int wave, int lane, int up_row_bias = 0, int nwaves = 4)
     {
         up_rb = up_row_bias;
         lds_a = la; lds_b = lb; c0 = c0_; c1 = c1_; g = geo; h = lane >> 5; r0 = r0_; nrows = nrows_;
@@ -184,8 +184,8 @@ struct ConvStage {
         wlane = (unsigned)lane;
         Rh = (nrows + g.TR - 1) / g.TR;
         const int tot = NSL * g.ncb * Rh;
-        f = (wave * tot) >> 2;
-        f1 = ((wave + 1) * tot) >> 2;
+        f = (wave * tot) / nwaves;
+        f1 = ((wave + 1) * tot) / nwaves;
         if (f < f1) {
             set_slice(unit_of(f) % NSL);
             prologue();

@@ -71,12 +71,12 @@ DEVI void conv_first_stage(const float *xs, const float *c0, int W, int r0, int 
     }
 }
 
-// Register-held payload of one LDS input tile: NP 16-byte items per thread (item i = tid + k*WG
+// Register-held payload of one LDS input tile: NP 16-byte items per thread (item i = tid + k*WGS
 // covers row i / (W*C/8), 8 channels).  load() reads rows [g0, g0+nrows) of a global NHWC bf16 map
 // (zeros outside [0,Hmap)); store() writes them into the tile (row t = global row g0+t) and clears
 // (unless HALO is false) the tile's two halo columns.  Splitting the two lets the loads of the next band fly while the
 // current band is still being computed.
-template <int C, int NP>
+template <int C, int NP, int WGS = WG>
 struct TileRegs {
     static constexpr int S = C * 2 + 16, CH = C / 8;
     bf16x8 v[NP];
@@ -88,7 +88,7 @@ struct TileRegs {
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, (unsigned)(Hmap * W * C * 2));
         const int ipr = W * CH;
         int row = tid / ipr, rem = tid - row * ipr;
-        const int drow = WG / ipr, drem = WG - drow * ipr;
+        const int drow = WGS / ipr, drem = WGS - drow * ipr;
         if (drem == 0) {  // a thread's items share one tile column: rows step by drow, offsets by a constant
             const int off0 = ((g0 + row) * ipr + rem) * 16;
 #pragma unroll
@@ -111,7 +111,7 @@ struct TileRegs {
     {
         const int ipr = W * CH;
         int row = tid / ipr, rem = tid - row * ipr;
-        const int drow = WG / ipr, drem = WG - drow * ipr;
+        const int drow = WGS / ipr, drem = WGS - drow * ipr;
         if (drem == 0) {
             char *p0 = tile + (row * (W + 2) + rem / CH + 1) * S + (rem % CH) * 16;
 #pragma unroll
@@ -130,7 +130,7 @@ struct TileRegs {
             bf16x8 z;
 #pragma unroll
             for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f;
-            for (int i = tid; i < nrows * 2 * CH; i += WG) {
+            for (int i = tid; i < nrows * 2 * CH; i += WGS) {
                 const int ch = i % CH, side = (i / CH) & 1, r = i / (2 * CH);
                 *(bf16x8 *)(tile + (r * (W + 2) + side * (W + 1)) * S + ch * 16) = z;
             }
@@ -139,19 +139,19 @@ struct TileRegs {
 };
 
 // Zeroes the halo columns of rows [0,nrows) and the whole of rows [z0,z1) of an LDS tile.
-template <int C>
+template <int C, int WGS = WG>
 DEVI void clear_halo(char *tile, int W, int nrows, int z0, int z1, int tid)
 {
     constexpr int S = C * 2 + 16, CH = C / 8;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < nrows * 2 * CH; i += WG) {
+    for (int i = tid; i < nrows * 2 * CH; i += WGS) {
         const int ch = i % CH, side = (i / CH) & 1, r = i / (2 * CH);
         *(f32x4 *)(tile + (r * (W + 2) + side * (W + 1)) * S + ch * 16) = z;
     }
     if (z1 > z0) {
         char *p = tile + z0 * (W + 2) * S;
         const int bytes = (z1 - z0) * (W + 2) * S;  // S is a multiple of 16
-        for (int i = tid * 16; i < bytes; i += WG * 16) *(f32x4 *)(p + i) = z;
+        for (int i = tid * 16; i < bytes; i += WGS * 16) *(f32x4 *)(p + i) = z;
     }
 }
 
@@ -184,10 +184,12 @@ extern "C" int idm_debug_timeline(long long *host)
 // OCC: wavefronts per SIMD the register budget is sized for (= workgroups per CU when LDS allows).
 // WT, RT: map width and band rows as compile-time constants (0 = taken from the arguments); the
 // specialised instances turn the index arithmetic of the tile copies into shifts and immediates.
-template <int MODE1, int CA, int CB, int C1, int C2, int EPI2, bool TADD, int NT1, int MS1, int WD1, int NT2, int MS2, int WD2, int NPA, int NPB, int OCC, int WT, int RT>
-__global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
+template <int MODE1, int CA, int CB, int C1, int C2, int EPI2, bool TADD, int NT1, int MS1, int WD1, int NT2, int MS2, int WD2, int NPA, int NPB, int OCC, int WT, int RT, int NW = 4>
+__global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WGS = NW * 64;   // threads per workgroup
+    static_assert(MODE1 != M1_FIRST || NW == 4, "the first-layer stage deals its tiles to four wavefronts");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = tid >> 6;
     const int h = lane >> 5;
@@ -225,11 +227,11 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
     float *cst = score_s - NCONST;
     const float *c_b1 = cst, *c_t1 = cst + C1, *c_b2 = cst + 2 * C1, *c_wh = c_b2 + C2, *c_bh = c_b2 + 2 * C2;
     (void)c_t1; (void)c_wh; (void)c_bh;
-    for (int i = tid; i < C1; i += WG) {
+    for (int i = tid; i < C1; i += WGS) {
         cst[i] = a.b1[i];
         cst[C1 + i] = TADD ? a.tadd1[i] : 0.0f;
     }
-    for (int i = tid; i < C2; i += WG) {
+    for (int i = tid; i < C2; i += WGS) {
         cst[2 * C1 + i] = a.b2[i];
         cst[2 * C1 + C2 + i] = EPI2 == E2_HEAD ? a.w_head[i] : 0.0f;
     }
@@ -243,8 +245,8 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
     Conv2 cs2;
     (void)cs1;
 
-    TileRegs<CAT, MODE1 == M1_FIRST ? 1 : NPA> ra;
-    TileRegs<CBT, MODE1 == M1_UPCAT ? NPB : 1> rb;
+    TileRegs<CAT, MODE1 == M1_FIRST ? 1 : NPA, WGS> ra;
+    TileRegs<CBT, MODE1 == M1_UPCAT ? NPB : 1, WGS> rb;
     float rx[MODE1 == M1_FIRST ? NPA : 1];
     (void)ra; (void)rb; (void)rx;
 
@@ -253,13 +255,13 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
     auto pf_load = [&](Item it) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        __builtin_assume(tid >= 0 && tid < WG);
+        __builtin_assume(tid >= 0 && tid < WGS);
         const int b = it.b, y0 = it.y0;
         if constexpr (MODE1 == M1_FIRST) {
             const float *x = (const float *)a.in_a + (size_t)b * Hx * Wx;
 #pragma unroll
             for (int k = 0; k < NPA; ++k) {
-                const int i = tid + k * WG, t = i / W, c = i - t * W, g = y0 - 2 + t;
+                const int i = tid + k * WGS, t = i / W, c = i - t * W, g = y0 - 2 + t;
                 rx[k] = (t < R + 4 && g >= 0 && g < Hx && c < Wx) ? x[(size_t)g * Wx + c] : 0.0f;
             }
         } else if constexpr (MODE1 == M1_PLAIN) {
@@ -273,15 +275,15 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
     auto pf_store = [&]() {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        __builtin_assume(tid >= 0 && tid < WG);
+        __builtin_assume(tid >= 0 && tid < WGS);
         if constexpr (MODE1 == M1_FIRST) {
             float *xs = (float *)lds_in;
 #pragma unroll
             for (int k = 0; k < NPA; ++k) {
-                const int i = tid + k * WG, t = i / W, c = i - t * W;
+                const int i = tid + k * WGS, t = i / W, c = i - t * W;
                 if (t < R + 4) xs[t * (W + 2) + c + 1] = rx[k];
             }
-            for (int i = tid; i < (R + 4) * 2; i += WG) xs[(i >> 1) * (W + 2) + (i & 1) * (W + 1)] = 0.0f;
+            for (int i = tid; i < (R + 4) * 2; i += WGS) xs[(i >> 1) * (W + 2) + (i & 1) * (W + 1)] = 0.0f;
         } else if constexpr (MODE1 == M1_PLAIN) {
             ra.store(tile_a, W, R + 4, tid);
         } else {
@@ -301,15 +303,15 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
         const int b = it.b, y0 = it.y0;
         const int rlo = y0 == 0 ? 1 : 0, rhi = min(R + 2, H - y0 + 1);
         const int tot = Conv1::NSL * geo.ncb * ((rhi - rlo + geo.TR - 1) / geo.TR);
-        int len[4], mn = 1 << 30;
+        int len[NW], mn = 1 << 30;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            len[w] = (((w + 1) * tot) >> 2) - ((w * tot) >> 2);
+        for (int w = 0; w < NW; ++w) {
+            len[w] = ((w + 1) * tot) / NW - (w * tot) / NW;
             mn = min(mn, len[w]);
         }
         int nl = 0, lr = 0, mine = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const int light = len[w] == mn;
             lr += light && w < wave;
             mine |= light && w == wave;
@@ -317,7 +319,8 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
         }
         const int rowsx = min(min(R, H - y0), Hx - y0);
         const int qrow = Wx >> 2, nq = max(rowsx, 0) * qrow;
-        const int qpw = nl == 4 ? (nq + 3) >> 2 : nl == 2 ? (nq + 1) >> 1 : nl == 1 ? nq : (nq + 2) / 3;
+        const int qpw = nl == 4 ? (nq + 3) >> 2 : nl == 2 ? (nq + 1) >> 1 : nl == 1 ? nq : nl == 3 ? (nq + 2) / 3
+                      : nl == 8 ? (nq + 7) >> 3 : nl == 6 ? (nq + 5) / 6 : (nq + nl - 1) / nl;
         q.path = WT ? true : ((Wx & 3) == 0 && qpw <= 64);
         const int qi = lr * qpw + lane;
         q.act = q.path && mine && lane < qpw && qi < nq;
@@ -341,14 +344,14 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
         if constexpr (MODE1 != M1_FIRST) {
             int rlo, rhi;
             band_geo(it, rlo, rhi);
-            cs1.begin(tile_a, tile_b, c_b1, c_t1, geo, rlo, rhi - rlo, (const bf16x8 *)a.w1, wave, lane);
+            cs1.begin(tile_a, tile_b, c_b1, c_t1, geo, rlo, rhi - rlo, (const bf16x8 *)a.w1, wave, lane, 0, NW);
         }
     };
 
-    clear_halo<C1>(lds_mid, W, R + 2, 0, 0, tid);  // halo columns of the mid tile: never written afterwards
+    clear_halo<C1, WGS>(lds_mid, W, R + 2, 0, 0, tid);  // halo columns of the mid tile: never written afterwards
     if constexpr (EPI2 == E2_HEAD && MODE1 == M1_UPCAT) {
-        clear_halo<CA>(tile_a, W >> 1, (R >> 1) + 2, 0, 0, tid);
-        clear_halo<CB>(tile_b, W, R + 4, 0, 0, tid);
+        clear_halo<CA, WGS>(tile_a, W >> 1, (R >> 1) + 2, 0, 0, tid);
+        clear_halo<CB, WGS>(tile_b, W, R + 4, 0, 0, tid);
     }
     int wg = blockIdx.x;
     Item cur = item_of(wg < total ? wg : 0);
@@ -369,8 +372,8 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
         TL(9);
         pf_store();
         // rows of the mid tile outside the map are conv2's zero padding (an earlier band may have left data there)
-        if (rlo) clear_halo<C1>(lds_mid, W, 0, 0, 1, tid);
-        if (rhi < R + 2) clear_halo<C1>(lds_mid, W, 0, rhi, R + 2, tid);
+        if (rlo) clear_halo<C1, WGS>(lds_mid, W, 0, 0, 1, tid);
+        if (rhi < R + 2) clear_halo<C1, WGS>(lds_mid, W, 0, rhi, R + 2, tid);
         TL(1);
         __syncthreads();
         TL(2);
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
         // the last iteration reloads its own band (discarded): an unconditional load keeps the prefetch
         // registers dead across the convolutions instead of loop-carried
         const Item nxt = item_of(wg + (int)gridDim.x < total ? wg + (int)gridDim.x : wg);
-        cs2.begin(lds_mid, nullptr, c_b2, c_wh, geo, 0, rows2, (const bf16x8 *)a.w2, wave, lane);
+        cs2.begin(lds_mid, nullptr, c_b2, c_wh, geo, 0, rows2, (const bf16x8 *)a.w2, wave, lane, 0, NW);
         if constexpr (EARLY_PF) {
             x_fetch(nxt);
             pf_load(nxt);
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
                 const int rowsx = min(rows2, Hx - y0);
                 float *xg = a.x + (size_t)b * Hx * Wx;
                 const size_t lat_off = (size_t)b * Hx * Wx;
-                for (int i = tid; i < rowsx * Wx; i += WG) {
+                for (int i = tid; i < rowsx * Wx; i += WGS) {
                     const int r = i / Wx, xc = i - r * Wx;
                     const int e = (y0 + r) * Wx + xc;
                     const float sc = score_s[r * W + xc];
@@ -511,14 +514,14 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
             TL(6);
             constexpr int CH = C2 / 8;
             __bf16 *og = (__bf16 *)a.out + ((size_t)b * H + y0) * W * C2;
-            for (int i = tid; i < npix2 * CH; i += WG) {
+            for (int i = tid; i < npix2 * CH; i += WGS) {
                 const int ch = i % CH, pos = i / CH;
                 *(bf16x8 *)(og + (size_t)pos * C2 + ch * 8) = *(const bf16x8 *)(stage + pos * SO + ch * 16);
             }
             if constexpr (EPI2 == E2_STORE_POOL) {
                 const int Wh = W >> 1, rh = rows2 >> 1;
                 __bf16 *pg = (__bf16 *)a.out_pool + ((size_t)b * (H >> 1) + (y0 >> 1)) * Wh * C2;
-                for (int i = tid; i < rh * Wh * CH; i += WG) {
+                for (int i = tid; i < rh * Wh * CH; i += WGS) {
                     const int ch = i % CH, pos = i / CH;
                     const int xh = pos % Wh, yh = pos / Wh;
                     const char *q = stage + ((2 * yh) * W + 2 * xh) * SO + ch * 16;
@@ -548,14 +551,23 @@ __global__ __launch_bounds__(WG, OCC) void fused2_kernel(FusedArgs a)
 namespace {
 
 // npa / npb: 16-byte items (FK_A: floats) per thread the kernel instance can hold in registers
-// for the next band's input tiles.
-struct KindInfo { int mode1, ca, cb, c1, c2, epi2, npa, npb; };
+// for the next band's input tiles; nw: wavefronts per workgroup.
+// IDM_B_WAVES = 8 builds fused_B with eight wavefronts and 16-row bands (one workgroup per CU): correct, but
+// 10 % slower than two four-wavefront workgroups per CU, whose barriers do not idle the whole CU.
+#ifndef IDM_B_WAVES
+#define IDM_B_WAVES 4
+#endif
+struct KindInfo { int mode1, ca, cb, c1, c2, epi2, npa, npb, nw; };
 constexpr KindInfo kKinds[5] = {
-    {M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, 3, 0},    // FK_A : x -> conv0 -> conv1 -> skip1, pooled
-    {M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, 5, 0},   // FK_M1: pooled -> conv2 -> conv3 -> skip2, pooled
-    {M1_PLAIN, 64, 0, 128, 128, E2_STORE, 3, 0},      // FK_M2: pooled -> conv4 (+time) -> conv5
-    {M1_UPCAT, 128, 64, 64, 64, E2_STORE, 5, 10},     // FK_M3: [up(conv5), skip2] -> conv6 -> conv7 (whole 16x16 map)
-    {M1_UPCAT, 64, 32, 32, 32, E2_HEAD, 3, 6},        // FK_B : [up(conv7), skip1] -> conv8 -> conv9 -> head -> update
+    {M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, 3, 0, 4},    // FK_A : x -> conv0 -> conv1 -> skip1, pooled
+    {M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, 5, 0, 4},   // FK_M1: pooled -> conv2 -> conv3 -> skip2, pooled
+    {M1_PLAIN, 64, 0, 128, 128, E2_STORE, 3, 0, 4},      // FK_M2: pooled -> conv4 (+time) -> conv5
+    {M1_UPCAT, 128, 64, 64, 64, E2_STORE, 5, 10, 4},     // FK_M3: [up(conv5), skip2] -> conv6 -> conv7 (whole 16x16 map)
+#if IDM_B_WAVES == 8
+    {M1_UPCAT, 64, 32, 32, 32, E2_HEAD, 3, 5, 8},     // FK_B : [up(conv7), skip1] -> conv8 -> conv9 -> head -> update (16-row bands)
+#else
+    {M1_UPCAT, 64, 32, 32, 32, E2_HEAD, 3, 6, 4},     // FK_B with four wavefronts and 8-row bands
+#endif
 };
 
 inline int align16(int v) { return (v + 15) & ~15; }
@@ -566,9 +578,24 @@ inline int align16(int v) { return (v + 15) & ~15; }
 bool fused_band_fits(int kind, int W, int R)
 {
     const KindInfo &k = kKinds[kind];
-    if (k.mode1 == M1_FIRST) return (R + 4) * W <= k.npa * WG;
-    if (k.mode1 == M1_PLAIN) return (R + 4) * W * (k.ca / 8) <= k.npa * WG;
-    return (R / 2 + 2) * (W / 2) * (k.ca / 8) <= k.npa * WG && (R + 4) * W * (k.cb / 8) <= k.npb * WG;
+    const int wg = k.nw * 64;
+    if (k.mode1 == M1_FIRST) return (R + 4) * W <= k.npa * wg;
+    if (k.mode1 == M1_PLAIN) return (R + 4) * W * (k.ca / 8) <= k.npa * wg;
+    return (R / 2 + 2) * (W / 2) * (k.ca / 8) <= k.npa * wg && (R + 4) * W * (k.cb / 8) <= k.npb * wg;
+}
+
+// Band height of the kinds that run one workgroup per CU, when it fits (0: use the two-per-CU rule).
+// FK_M3 (conv6 + conv7: widest K, 25 % halo recompute at 8 rows) takes the whole map; FK_B with eight
+// wavefronts takes 16 rows (halo 2 of 18 instead of 2 of 10, half the per-band bookkeeping).
+int fused_tall_rows(int kind, int H, int W)
+{
+    int R = 0;
+    if (kind == FK_M3) R = H;
+    else if (kind == FK_B && kKinds[kind].nw == 8) R = H < 16 ? H : 16;
+    if (R <= 0 || (R & 1)) return 0;
+    int in = 0, mid = 0;
+    fused_lds_bytes(kind, W, R, &in, &mid);
+    return in + mid <= 159 * 1024 && fused_band_fits(kind, W, R) ? R : 0;
 }
 
 void fused_lds_bytes(int kind, int W, int R, int *in_bytes, int *mid_bytes)
@@ -593,7 +620,7 @@ struct LaunchState {
 };
 
 template <class K>
-static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int64_t B, hipStream_t s)
+static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int64_t B, hipStream_t s, int threads = WG)
 {
     const int lds = a.lds_in_bytes + a.lds_mid_bytes;
     if (!st.configured) {
@@ -607,7 +634,7 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
     }
     if (st.cached_lds != lds) {
         int n = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kernel, WG, (size_t)lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kernel, threads, (size_t)lds);
         if (e != hipSuccess) return e;
         st.cached_blocks = n > 0 ? n : 1;
         st.cached_lds = lds;
@@ -615,7 +642,7 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
     const int64_t total = B * a.nbands;
     if (total >= ((int64_t)1 << 31)) return hipErrorInvalidValue;   // the kernels index work items in 32 bits
     const int64_t grid = std::min<int64_t>(total, (int64_t)st.cus * st.cached_blocks);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WG), lds, s, a);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, s, a);
     return hipGetLastError();
 }
 
@@ -633,7 +660,11 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
 #define IDM_CFG_M3 4, 1, 2, 4, 1, 3, 5, 10, 1
 #endif
 #ifndef IDM_CFG_B
+#if IDM_B_WAVES == 8
+#define IDM_CFG_B 3, 1, 2, 2, 1, 3, 3, 5, 1
+#else
 #define IDM_CFG_B 3, 1, 2, 2, 1, 3, 3, 6, 2
+#endif
 #endif
 
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
@@ -643,7 +674,7 @@ hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
     if (slot < 0) return hipErrorInvalidDevice;
     LaunchState *st = all_st[slot];
     // instances specialised for the L = 32 pyramid (widths 32 / 16 / 8; 8-row bands, M3 the whole 16-row map; no padding)
-    const int w32[5] = {32, 16, 8, 16, 32}, r32[5] = {8, 8, 8, 16, 8};
+    const int w32[5] = {32, 16, 8, 16, 32}, r32[5] = {8, 8, 8, 16, IDM_B_WAVES == 8 ? 16 : 8};
     const bool spec = a.W == w32[kind] && a.R == r32[kind] && a.Hx == 32 && a.Wx == 32;
     if (spec) {
         switch (kind) {
@@ -651,7 +682,7 @@ hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
         case FK_M1: return launch_one(st[6], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1, 16, 8>, a, B, s);
         case FK_M2: return launch_one(st[7], fused2_kernel<M1_PLAIN, 64, 0, 128, 128, E2_STORE, true, IDM_CFG_M2, 8, 8>, a, B, s);
         case FK_M3: return launch_one(st[8], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, IDM_CFG_M3, 16, 16>, a, B, s);
-        default: return launch_one(st[9], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, IDM_CFG_B, 32, 8>, a, B, s);
+        default: return launch_one(st[9], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, IDM_CFG_B, 32, IDM_B_WAVES == 8 ? 16 : 8, IDM_B_WAVES>, a, B, s, IDM_B_WAVES * 64);
         }
     }
     switch (kind) {
@@ -659,6 +690,6 @@ hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
     case FK_M1: return launch_one(st[1], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1, 0, 0>, a, B, s);
     case FK_M2: return launch_one(st[2], fused2_kernel<M1_PLAIN, 64, 0, 128, 128, E2_STORE, true, IDM_CFG_M2, 0, 0>, a, B, s);
     case FK_M3: return launch_one(st[3], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, IDM_CFG_M3, 0, 0>, a, B, s);
-    default: return launch_one(st[4], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, IDM_CFG_B, 0, 0>, a, B, s);
+    default: return launch_one(st[4], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, IDM_CFG_B, 0, 0, IDM_B_WAVES>, a, B, s, IDM_B_WAVES * 64);
     }
 }

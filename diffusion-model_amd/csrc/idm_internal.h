@@ -114,6 +114,7 @@ struct FusedArgs {
 
 void fused_lds_bytes(int kind, int W, int R, int *in_bytes, int *mid_bytes);
 bool fused_band_fits(int kind, int W, int R);
+int fused_tall_rows(int kind, int H, int W);
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s);
 
 // ---- single-convolution band/strip kernels (idm_strip.hip) ----

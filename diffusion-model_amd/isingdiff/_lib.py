@@ -91,6 +91,7 @@ SIGNATURES = {
     "idm_mlp_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(MlpDesc)]),
     "idm_mlp_destroy": (C.c_int, [C.c_void_p]),
     "idm_mlp_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "idm_mlp_forward_precision": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "idm_mlp_sample": (C.c_int, [C.c_void_p, C.POINTER(SampleCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                  C.c_void_p]),
     "idm_bitflip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(BitflipDesc)]),

@@ -111,7 +111,7 @@ class BitflipModel:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h and _lib._lib is not None:
+        if h and _lib is not None and getattr(_lib, "_lib", None) is not None:   # (module globals may be gone at exit)
             _lib._lib.idm_bitflip_destroy(h)
 
     def _stream(self):

@@ -66,11 +66,16 @@ def load_dense_spec(path: str) -> DenseSpec:
 
 class DenseScoreModel:
     """``score_model(xt)`` of the reference: xt (B, n+1) = [x | t_norm] with one shared t_norm per call
-    (as ``diffusion_backward`` builds it); returns the score (B, n) float32 (torch, on the GPU)."""
+    (as ``diffusion_backward`` builds it); returns the score (B, n) float32 (torch, on the GPU).
+    ``precision``: "fp32" (canonical arithmetic, bit-exact against the CPU restatement) or "bf16"
+    (Dense layers on bf16 MFMA, float32 accumulation and state)."""
 
-    def __init__(self, spec: DenseSpec, device: int = 0):
+    def __init__(self, spec: DenseSpec, device: int = 0, precision: str = "fp32"):
         import torch
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
         self.torch, self.spec, self.device, self.n = torch, spec, device, spec.n
+        self.precision = _lib.IDM_BF16 if precision == "bf16" else _lib.IDM_FP32
         d = _lib.MlpDesc()
         d.n_layers = len(spec.kernels)
         if d.n_layers > _lib.MLP_MAXLAYERS:
@@ -85,7 +90,7 @@ class DenseScoreModel:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h and _lib._lib is not None:
+        if h and _lib is not None and getattr(_lib, "_lib", None) is not None:   # (module globals may be gone at exit)
             _lib._lib.idm_mlp_destroy(h)
 
     def _stream(self):
@@ -102,8 +107,8 @@ class DenseScoreModel:
             raise ValueError(f"x must be (B, {self.n})")
         out = self.torch.empty_like(x)
         with self.torch.cuda.device(self.device):
-            _lib.check(_lib.load().idm_mlp_forward(self._h, x.data_ptr(), float(np.float32(t_norm)), out.data_ptr(),
-                                                   x.shape[0], self._stream()))
+            _lib.check(_lib.load().idm_mlp_forward_precision(self._h, x.data_ptr(), float(np.float32(t_norm)), out.data_ptr(),
+                                                             x.shape[0], self.precision, self._stream()))
         return out
 
     def __call__(self, xt):
@@ -116,8 +121,8 @@ class DenseScoreModel:
         return self.score(xt[:, :self.n].contiguous(), float(t[0]))
 
 
-def load_dense_model(path: str, device: int = 0) -> DenseScoreModel:
-    return DenseScoreModel(load_dense_spec(path), device)
+def load_dense_model(path: str, device: int = 0, precision: str = "fp32") -> DenseScoreModel:
+    return DenseScoreModel(load_dense_spec(path), device, precision)
 
 
 def diffusion_backward(x_asym, beta_lst, score_model: DenseScoreModel, T: int, *, noise=None, seed: int = 42,
@@ -137,7 +142,7 @@ def diffusion_backward(x_asym, beta_lst, score_model: DenseScoreModel, T: int, *
         if tuple(z.shape) != (T, B, n):
             raise ValueError("noise must be (T, B, n)")
     traj = torch.empty((T + 1, B, n), dtype=torch.float32, device=x.device) if return_trajectory else None
-    cfg = _lib.SampleCfg(T=T, precision=_lib.IDM_FP32, betas_host=betas.ctypes.data, seed=seed,
+    cfg = _lib.SampleCfg(T=T, precision=score_model.precision, betas_host=betas.ctypes.data, seed=seed,
                          first_global_index=first_global_index, init_state=0, add_noise=int(noise is not False), chunk=0)
     with torch.cuda.device(score_model.device):
         _lib.check(_lib.load().idm_mlp_sample(score_model._h, C.byref(cfg), x.data_ptr(), None if z is None else z.data_ptr(),

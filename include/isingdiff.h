@@ -231,7 +231,9 @@ int idm_bitflip_sample(idm_bitflip *m, const idm_bitflip_cfg *cfg, uint8_t *x_de
 /* ---------------------------------------------------------------------------------------------
  * Dense spectral score model (b_diffusion_model_fft_2d_ising.py:105-114: Sequential of Dense
  * layers on [x | t_norm], saved as models/b_diffusion_model_2d_ising.keras) and its sampler
- * (:19-38).  Float32 parity mode (canonical arithmetic).  Layer widths up to 448. */
+ * (:19-38).  IDM_FP32: parity mode (canonical arithmetic); IDM_BF16: the Dense layers on bf16 MFMA with
+ * float32 accumulation, float32 state, the t_norm column applied in float32.  Layer widths up to 448
+ * (IDM_BF16: multiples of 4). */
 #define IDM_MLP_MAXLAYERS 8
 
 typedef struct {
@@ -252,7 +254,11 @@ int idm_mlp_destroy(idm_mlp *m);
 /* score = score_model(concat([x, t_norm])) (:28-30).  x_dev, score_dev (B, n) float32. */
 int idm_mlp_forward(idm_mlp *m, const float *x_dev, float t_norm, float *score_dev, int64_t B, void *stream);
 
-/* diffusion_backward (:19-38): cfg as for idm_sample (precision must be IDM_FP32; chunk unused).
+/* The same in the given precision (IDM_FP32 is idm_mlp_forward). */
+int idm_mlp_forward_precision(idm_mlp *m, const float *x_dev, float t_norm, float *score_dev, int64_t B, int precision,
+                              void *stream);
+
+/* diffusion_backward (:19-38): cfg as for idm_sample (chunk unused); both precisions draw the same noise.
  * x_dev (B, n): x_T on entry (or drawn here when cfg->init_state), final state on return;
  * noise_dev NULL or (T, B, n) standard normals indexed by t; traj_dev NULL or (T+1, B, n) with
  * traj[T] = x_T and traj[t] = state after step t (the reference's return layout). */

@@ -557,12 +557,15 @@ namespace {
 #ifndef IDM_B_WAVES
 #define IDM_B_WAVES 4
 #endif
+#ifndef IDM_M3_WAVES
+#define IDM_M3_WAVES 4
+#endif
 struct KindInfo { int mode1, ca, cb, c1, c2, epi2, npa, npb, nw; };
 constexpr KindInfo kKinds[5] = {
     {M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, 3, 0, 4},    // FK_A : x -> conv0 -> conv1 -> skip1, pooled
     {M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, 5, 0, 4},   // FK_M1: pooled -> conv2 -> conv3 -> skip2, pooled
     {M1_PLAIN, 64, 0, 128, 128, E2_STORE, 3, 0, 4},      // FK_M2: pooled -> conv4 (+time) -> conv5
-    {M1_UPCAT, 128, 64, 64, 64, E2_STORE, 5, 10, 4},     // FK_M3: [up(conv5), skip2] -> conv6 -> conv7 (whole 16x16 map)
+    {M1_UPCAT, 128, 64, 64, 64, E2_STORE, IDM_M3_WAVES == 8 ? 3 : 5, IDM_M3_WAVES == 8 ? 5 : 10, IDM_M3_WAVES},     // FK_M3: [up(conv5), skip2] -> conv6 -> conv7 (whole 16x16 map)
 #if IDM_B_WAVES == 8
     {M1_UPCAT, 64, 32, 32, 32, E2_HEAD, 3, 5, 8},     // FK_B : [up(conv7), skip1] -> conv8 -> conv9 -> head -> update (16-row bands)
 #else
@@ -681,7 +684,7 @@ hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
         case FK_A: return launch_one(st[5], fused2_kernel<M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, false, IDM_CFG_A, 32, 8>, a, B, s);
         case FK_M1: return launch_one(st[6], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1, 16, 8>, a, B, s);
         case FK_M2: return launch_one(st[7], fused2_kernel<M1_PLAIN, 64, 0, 128, 128, E2_STORE, true, IDM_CFG_M2, 8, 8>, a, B, s);
-        case FK_M3: return launch_one(st[8], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, IDM_CFG_M3, 16, 16>, a, B, s);
+        case FK_M3: return launch_one(st[8], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, IDM_CFG_M3, 16, 16, IDM_M3_WAVES>, a, B, s, IDM_M3_WAVES * 64);
         default: return launch_one(st[9], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, IDM_CFG_B, 32, IDM_B_WAVES == 8 ? 16 : 8, IDM_B_WAVES>, a, B, s, IDM_B_WAVES * 64);
         }
     }
@@ -689,7 +692,7 @@ hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
     case FK_A: return launch_one(st[0], fused2_kernel<M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, false, IDM_CFG_A, 0, 0>, a, B, s);
     case FK_M1: return launch_one(st[1], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1, 0, 0>, a, B, s);
     case FK_M2: return launch_one(st[2], fused2_kernel<M1_PLAIN, 64, 0, 128, 128, E2_STORE, true, IDM_CFG_M2, 0, 0>, a, B, s);
-    case FK_M3: return launch_one(st[3], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, IDM_CFG_M3, 0, 0>, a, B, s);
+    case FK_M3: return launch_one(st[3], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, IDM_CFG_M3, 0, 0, IDM_M3_WAVES>, a, B, s, IDM_M3_WAVES * 64);
     default: return launch_one(st[4], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, IDM_CFG_B, 0, 0, IDM_B_WAVES>, a, B, s, IDM_B_WAVES * 64);
     }
 }

@@ -348,6 +348,11 @@ bool strip_fits(int kind, int R, int WS)
     (a.WS == 32 && a.R == R8 ? launch_strip_one(st[SK_COUNT + idx], strip_kernel<__VA_ARGS__, 32, R8>, a, s)   \
                              : launch_strip_one(st[idx], strip_kernel<__VA_ARGS__, 0, 0>, a, s))
 
+// Weight ring depth of the strip kernels (supersteps fetched ahead).
+#ifndef IDM_STRIP_WD
+#define IDM_STRIP_WD 2
+#endif
+
 hipError_t launch_strip(int kind, const StripArgs &a, hipStream_t s)
 {
     static thread_local StripLaunch all_st[IDM_MAX_DEVICES][2 * SK_COUNT];
@@ -356,15 +361,15 @@ hipError_t launch_strip(int kind, const StripArgs &a, hipStream_t s)
     StripLaunch *st = all_st[slot];
     // second argument: the band height make_plan picks for 32-column strips (specialised instance)
     switch (kind) {
-    case SK_CONV1: return STRIP_INST(0, 8, 32, 0, false, 32, SE_STORE_POOL, false, 3, 1, 3, 6, 0, 2);
-    case SK_CONV2: return STRIP_INST(1, 8, 32, 0, false, 64, SE_STORE, false, 3, 1, 3, 6, 0, 2);
-    case SK_CONV3: return STRIP_INST(2, 4, 64, 0, false, 64, SE_STORE_POOL, false, 3, 1, 3, 11, 0, 2);
-    case SK_CONV4: return STRIP_INST(3, 4, 64, 0, false, 128, SE_STORE, true, 3, 1, 3, 11, 0, 2);
-    case SK_CONV5: return STRIP_INST(4, 2, 128, 0, false, 128, SE_STORE, false, 3, 1, 3, 11, 0, 2);
-    case SK_CONV6: return STRIP_INST(5, 4, 128, 64, true, 64, SE_STORE, false, 3, 1, 3, 7, 11, 2);
-    case SK_CONV7: return STRIP_INST(6, 4, 64, 0, false, 64, SE_STORE, false, 3, 1, 3, 11, 0, 2);
-    case SK_CONV8: return STRIP_INST(7, 8, 64, 32, true, 32, SE_STORE, false, 3, 1, 3, 4, 6, 2);
-    case SK_CONV9: return STRIP_INST(8, 8, 32, 0, false, 32, SE_HEAD, false, 3, 1, 3, 6, 0, 2);
-    default: return STRIP_INST(9, 8, 32, 0, false, 32, SE_STORE, false, 3, 1, 3, 6, 0, 2);
+    case SK_CONV1: return STRIP_INST(0, 8, 32, 0, false, 32, SE_STORE_POOL, false, 3, 1, IDM_STRIP_WD, 6, 0, 2);
+    case SK_CONV2: return STRIP_INST(1, 8, 32, 0, false, 64, SE_STORE, false, 3, 1, IDM_STRIP_WD, 6, 0, 2);
+    case SK_CONV3: return STRIP_INST(2, 4, 64, 0, false, 64, SE_STORE_POOL, false, 3, 1, IDM_STRIP_WD, 11, 0, 2);
+    case SK_CONV4: return STRIP_INST(3, 4, 64, 0, false, 128, SE_STORE, true, 3, 1, IDM_STRIP_WD, 11, 0, 2);
+    case SK_CONV5: return STRIP_INST(4, 2, 128, 0, false, 128, SE_STORE, false, 3, 1, IDM_STRIP_WD, 11, 0, 2);
+    case SK_CONV6: return STRIP_INST(5, 4, 128, 64, true, 64, SE_STORE, false, 3, 1, IDM_STRIP_WD, 7, 11, 2);
+    case SK_CONV7: return STRIP_INST(6, 4, 64, 0, false, 64, SE_STORE, false, 3, 1, IDM_STRIP_WD, 11, 0, 2);
+    case SK_CONV8: return STRIP_INST(7, 8, 64, 32, true, 32, SE_STORE, false, 3, 1, IDM_STRIP_WD, 4, 6, 2);
+    case SK_CONV9: return STRIP_INST(8, 8, 32, 0, false, 32, SE_HEAD, false, 3, 1, IDM_STRIP_WD, 6, 0, 2);
+    default: return STRIP_INST(9, 8, 32, 0, false, 32, SE_STORE, false, 3, 1, IDM_STRIP_WD, 6, 0, 2);
     }
 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round measurement on one GPU box: default bench, the same command under rocprofv3 --kernel-trace --stats,
+# Full measurement on one GPU box: default bench, the same command under rocprofv3 --kernel-trace --stats,
 # and the two HBM counter passes (FETCH_SIZE, WRITE_SIZE) on a short slice of the schedule.
 # Outputs under gpurun_out/measure/.
 set -o pipefail

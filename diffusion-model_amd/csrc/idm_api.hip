@@ -91,6 +91,8 @@ int idm_set_error(int code, const char *msg) { return fail(code, msg ? msg : "")
 
 std::vector<float> idm_pack_weights_f32(const float *w, int cin, int cout) { return pack_weights_f32(w, cin, cout); }
 
+std::vector<uint16_t> idm_pack_weights_bf16(const float *w, int cin, int cout) { return pack_weights_bf16(w, cin, cout); }
+
 std::vector<float> idm_pack_weights_f32_1x1(const float *w, int cin, int cout)
 {
     const int ncg = cin / 8, mt = cout / 32;

@@ -113,15 +113,17 @@ __global__ __launch_bounds__(256) void bf_gn_stats_kernel(const float *__restric
     }
 }
 
+// OutT = float (parity mode) or __bf16 (the operand of the bf16 convolution)
+template <typename OutT>
 __global__ __launch_bounds__(256) void bf_gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ ab,
-                                                          float *__restrict__ y, int64_t n, int HW, int C)
+                                                          OutT *__restrict__ y, int64_t n, int HW, int C)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int c = (int)(i % C);
     const int64_t b = i / ((int64_t)HW * C);
     const float a = ab[(b * C + c) * 2], sh = ab[(b * C + c) * 2 + 1];
-    y[i] = csilu(__fadd_rn(__fmul_rn(x[i], a), sh));
+    y[i] = (OutT)csilu(__fadd_rn(__fmul_rn(x[i], a), sh));
 }
 
 // out = (conv1x1(x) + bias) + h  (the ResBlock's projected shortcut, :188-192); w == nullptr: out = x + h.
@@ -218,6 +220,8 @@ struct idm_bitflip {
     int device = 0;
     const float *t[IDM_BITFLIP_NTENSOR] = {};   // device copies, Keras layouts
     void *c1_pack[NBLK] = {}, *c2_pack[NBLK] = {}, *s_pack[NBLK] = {};
+    void *c1_pack16[NBLK] = {}, *c2_pack16[NBLK] = {};   // bf16 fragments of the 3x3 kernels
+    int precision = IDM_FP32;
     float *emb_dev = nullptr;   // (T, EMB) scratch for the embedding rows
     int emb_cap = 0;
     float *tvec = nullptr;      // (T, TVEC)
@@ -305,21 +309,28 @@ int time_vectors(idm_bitflip *m, const float *emb_host, int rows, hipStream_t s)
     return IDM_OK;
 }
 
-void gn_silu(const float *x, int64_t B, int HW, int C, const float *gamma, const float *beta, float *ab, float *y, hipStream_t s)
+// y: float32, or bf16 in the same buffer when `half`
+void gn_silu(const float *x, int64_t B, int HW, int C, const float *gamma, const float *beta, float *ab, float *y, bool half,
+             hipStream_t s)
 {
     hipLaunchKernelGGL(bf_gn_stats_kernel, dim3((unsigned)((B * 8 + 3) / 4)), dim3(256), 0, s, x, B, HW, C, gamma, beta, ab);
     const int64_t n = B * HW * C;
-    hipLaunchKernelGGL(bf_gn_apply_kernel, dim3(blocks(n)), dim3(256), 0, s, x, (const float *)ab, y, n, HW, C);
+    if (half)
+        hipLaunchKernelGGL(bf_gn_apply_kernel<__bf16>, dim3(blocks(n)), dim3(256), 0, s, x, (const float *)ab, (__bf16 *)y, n, HW, C);
+    else
+        hipLaunchKernelGGL(bf_gn_apply_kernel<float>, dim3(blocks(n)), dim3(256), 0, s, x, (const float *)ab, y, n, HW, C);
 }
 
+// half: `in` holds bf16 and wpack bf16 fragments -> bf16 MFMA kernel (float32 accumulation and output)
 void conv3(const float *in, int64_t B, int H, int W, int Cin, const void *wpack, const float *bias, const float *tadd,
-           float *out, int Cout, hipStream_t s)
+           float *out, int Cout, bool half, hipStream_t s)
 {
     ConvArgs a = {};
     a.in0 = in; a.in1 = nullptr; a.C0 = Cin; a.C1 = 0; a.H = H; a.W = W; a.B = B; a.wpack = wpack; a.bias = bias;
     a.scale = nullptr; a.shift = nullptr; a.tadd = tadd; a.out = out; a.Cout = Cout; a.mode = CONV_PLAIN; a.silu = 0;
     a.out_f32 = 1;
-    launch_conv_f32(a, s);
+    if (half) launch_conv_bf16(a, s);
+    else launch_conv_f32(a, s);
 }
 
 // ResBlock (:168-193).  ta: >= B*H*W*max(Cin,width) floats, tbuf: >= B*H*W*width floats.
@@ -327,10 +338,11 @@ void resblock(idm_bitflip *m, int i, const float *x, int64_t B, int H, int W, co
               float *tbuf, float *ab, hipStream_t s)
 {
     const int Cin = kCin[i], Cw = kWidth[i], HW = H * W;
-    gn_silu(x, B, HW, Cin, m->t[tb(i, K_G1_G)], m->t[tb(i, K_G1_B)], ab, ta, s);
-    conv3(ta, B, H, W, Cin, m->c1_pack[i], m->t[tb(i, K_C1_B)], tvec, tbuf, Cw, s);
-    gn_silu(tbuf, B, HW, Cw, m->t[tb(i, K_G2_G)], m->t[tb(i, K_G2_B)], ab, ta, s);
-    conv3(ta, B, H, W, Cw, m->c2_pack[i], m->t[tb(i, K_C2_B)], nullptr, tbuf, Cw, s);
+    const bool half = m->precision == IDM_BF16;
+    gn_silu(x, B, HW, Cin, m->t[tb(i, K_G1_G)], m->t[tb(i, K_G1_B)], ab, ta, half, s);
+    conv3(ta, B, H, W, Cin, half ? m->c1_pack16[i] : m->c1_pack[i], m->t[tb(i, K_C1_B)], tvec, tbuf, Cw, half, s);
+    gn_silu(tbuf, B, HW, Cw, m->t[tb(i, K_G2_G)], m->t[tb(i, K_G2_B)], ab, ta, half, s);
+    conv3(ta, B, H, W, Cw, half ? m->c2_pack16[i] : m->c2_pack[i], m->t[tb(i, K_C2_B)], nullptr, tbuf, Cw, half, s);
     const int64_t npix = B * HW;
     if (m->s_pack[i]) {
         // projected shortcut (:188-192) on the matrix cores: the centre tap alone is a 1x1 convolution with the
@@ -431,6 +443,16 @@ int idm_bitflip_create(idm_bitflip **out, int device, const idm_bitflip_desc *d)
             float *pd = nullptr;
             rc = bf_upload(m, pk.data(), pk.size(), &pd);
             (k == K_C1_W ? m->c1_pack : m->c2_pack)[blk] = pd;
+            if (rc == IDM_OK) {
+                std::vector<uint16_t> ph = idm_pack_weights_bf16(d->tensors[i], ci, kWidth[blk]);
+                void *hd = nullptr;
+                if (hipMalloc(&hd, ph.size() * 2) != hipSuccess) rc = idm_set_error(IDM_ERR_NOMEM, "bit-flip weight allocation failed");
+                else {
+                    m->owned.push_back(hd);
+                    (void)hipMemcpy(hd, ph.data(), ph.size() * 2, hipMemcpyHostToDevice);
+                    (k == K_C1_W ? m->c1_pack16 : m->c2_pack16)[blk] = hd;
+                }
+            }
         }
         if (rc == IDM_OK && in_blk && k == K_S_W) {
             std::vector<float> pk = idm_pack_weights_f32_1x1(d->tensors[i], kCin[blk], kWidth[blk]);
@@ -444,6 +466,14 @@ int idm_bitflip_create(idm_bitflip **out, int device, const idm_bitflip_desc *d)
         return rc;
     }
     *out = m;
+    return IDM_OK;
+}
+
+int idm_bitflip_set_precision(idm_bitflip *m, int precision)
+{
+    if (!m) return idm_set_error(IDM_ERR_INVALID, "null model");
+    if (precision != IDM_FP32 && precision != IDM_BF16) return idm_set_error(IDM_ERR_INVALID, "unknown precision");
+    m->precision = precision;
     return IDM_OK;
 }
 

@@ -10,6 +10,7 @@
 int idm_set_error(int code, const char *msg);
 // Keras kernel (3,3,Cin,Cout) -> float A operands of v_mfma_f32_32x32x2_f32, [tap][c/8][mt][lane][4].
 std::vector<float> idm_pack_weights_f32(const float *w, int cin, int cout);
+std::vector<uint16_t> idm_pack_weights_bf16(const float *w, int cin, int cout);   // (3,3,Cin,Cout) -> bf16 MFMA A fragments
 // the same for a (Cin,Cout) 1x1 kernel: one tap
 std::vector<float> idm_pack_weights_f32_1x1(const float *w, int cin, int cout);
 

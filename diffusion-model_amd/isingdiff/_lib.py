@@ -96,6 +96,7 @@ SIGNATURES = {
                                  C.c_void_p]),
     "idm_bitflip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(BitflipDesc)]),
     "idm_bitflip_destroy": (C.c_int, [C.c_void_p]),
+    "idm_bitflip_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "idm_bitflip_time": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "idm_bitflip_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p), C.c_void_p]),

@@ -84,8 +84,10 @@ class BitflipModel:
     """``model([X, t_tensor])`` of the reference (``:48``): X (B,H,W,1) bool / 0-1, t_tensor (B,) with one
     shared value ``t / time_step``; returns the flip probabilities (B,H,W,1) float32 (torch, on the GPU)."""
 
-    def __init__(self, weights: dict, device: int = 0, time_step: int = 100):
+    def __init__(self, weights: dict, device: int = 0, time_step: int = 100, precision: str = "fp32"):
         import torch
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
         self.torch = torch
         self.device = device
         self.time_step = time_step
@@ -108,6 +110,8 @@ class BitflipModel:
         with torch.cuda.device(device):
             _lib.check(_lib.load().idm_bitflip_create(C.byref(h), device, C.byref(desc)))
         self._h = h
+        if precision == "bf16":     # 3x3 convolutions on bf16 MFMA; "fp32" is the bit-exact parity mode
+            _lib.check(_lib.load().idm_bitflip_set_precision(h, _lib.IDM_BF16))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

@@ -212,6 +212,11 @@ typedef struct idm_bitflip idm_bitflip;
 int idm_bitflip_create(idm_bitflip **out, int device, const idm_bitflip_desc *desc);
 int idm_bitflip_destroy(idm_bitflip *m);
 
+/* IDM_FP32 (default): canonical float32 arithmetic, bit-exact against the CPU restatement.  IDM_BF16: the
+ * 3x3 convolutions of the ResBlocks take bf16 operands (GroupNorm + swish output and weights rounded to
+ * bf16) on bf16 MFMA with float32 accumulation; everything else stays float32. */
+int idm_bitflip_set_precision(idm_bitflip *m, int precision);
+
 /* The five per-block time vectors swish(Dense_i(temb)) (:173, :200-203) for one embedding row
  * (32 host floats): 320 device floats.  Synchronises.  For tests. */
 int idm_bitflip_time(idm_bitflip *m, const float *emb_host, float *tvec_dev);

@@ -1,5 +1,6 @@
 """GPU parity of the MNIST bit-flip sampler (mnist_diffusion/mnist_diffusion.py:43-52, :162-240),
-through the C-ABI, against the C oracle: float32 canonical arithmetic, so everything is bit-exact.
+through the C-ABI, against the C oracle: float32 canonical arithmetic, so everything is bit-exact; the bf16
+convolution mode within a stated tolerance of the float32 oracle.
 
 Parity unpinned by the reference (no weights or outputs shipped): synthetic weights, oracle =
 oracle/ref_bitflip.c, itself cross-checked against the PyTorch restatement in the CPU suite."""
@@ -87,3 +88,52 @@ def test_flip_rate_follows_probability(setup):
     traj = bitflip.diffusion_backward(x0, model, 100, seed=3).cpu().numpy()
     flipped = traj[1].astype(np.float64).mean()
     assert abs(flipped - p.mean()) < 4 * np.sqrt(p.mean() * (1 - p.mean()) / p.size) + 1e-3
+
+
+BF16_PROBA_ABS = 2e-2      # bf16 convolution mode: flip probabilities against the float32 oracle, max abs error
+BF16_TAP_REL_L2 = 2e-2     # ... and every ResBlock output, relative L2
+
+
+@pytest.fixture(scope="module")
+def fast(setup):
+    bitflip, model, ref = setup
+    return bitflip.BitflipModel(model.weights, device=0, time_step=100, precision="bf16")
+
+
+@pytest.mark.parametrize("hw", [(28, 28), (12, 20)])
+def test_bf16_forward_within_tolerance(setup, fast, hw):
+    bitflip, model, ref = setup
+    H, W = hw
+    rs = np.random.RandomState(6)
+    x = (rs.rand(5, H, W) < 0.5).astype(np.uint8)
+    emb = bitflip.sinusoidal_table(100)
+    for t in (99, 30, 0):
+        p, taps = fast([x[..., None], np.full(5, np.float32(t) / np.float32(100), np.float32)], taps=True)
+        pr, tr = ref.forward(x, emb[t], taps=True)
+        for i, (a, b) in enumerate(zip(taps, tr)):
+            a = a.cpu().numpy()
+            assert np.all(np.isfinite(a))
+            assert np.linalg.norm(a - b) <= BF16_TAP_REL_L2 * np.linalg.norm(b), f"ResBlock {i} at t={t}"
+        assert np.max(np.abs(p.cpu().numpy()[..., 0] - pr)) <= BF16_PROBA_ABS
+
+
+def test_bf16_sampler_flips_like_float32(setup, fast):
+    bitflip, model, ref = setup
+    rs = np.random.RandomState(7)
+    B, T = 16, 100
+    x0 = (rs.rand(B, 28, 28, 1) < 0.5).astype(np.uint8)
+    u = rs.rand(T, B, 28, 28).astype(np.float32)
+    a = bitflip.diffusion_backward(x0, model, T, uniforms=u).cpu().numpy()
+    b = bitflip.diffusion_backward(x0, fast, T, uniforms=u).cpu().numpy()
+    assert a.shape == b.shape == (T + 1, B, 28, 28, 1) and np.array_equal(b[0], x0)
+    # same uniforms: a pixel flips differently only where u lies within the probability error of p, so the
+    # one-step disagreement stays at the percent level (the states then evolve apart, as any perturbation would)
+    assert np.mean(a[1] != b[1]) <= 0.03
+    # and the flip statistics agree over the whole schedule
+    fa, fb = np.mean(a[1:] != a[:-1]), np.mean(b[1:] != b[:-1])
+    assert abs(fa - fb) <= 0.02 * max(fa, 1e-3) + 2e-3
+    # Philox uniforms: independent of sharding in bf16 mode too
+    w = bitflip.diffusion_backward(x0, fast, T, seed=3, return_trajectory=False).cpu().numpy()
+    h1 = bitflip.diffusion_backward(x0[:5], fast, T, seed=3, return_trajectory=False).cpu().numpy()
+    h2 = bitflip.diffusion_backward(x0[5:], fast, T, seed=3, first_global_index=5, return_trajectory=False).cpu().numpy()
+    assert np.array_equal(w, np.concatenate([h1, h2]))

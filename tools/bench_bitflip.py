@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Throughput of the MNIST bit-flip sampler (float32 parity-mode kernels): B images through the
+"""Throughput of the MNIST bit-flip sampler (float32 parity-mode kernels, then the bf16 convolution mode): B images through the
 whole 100-step schedule.  Prints one JSON line (not the repository's headline bench)."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,15 +9,16 @@ import torch
 from isingdiff import bitflip
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-model = bitflip.BitflipModel(bitflip.synthetic_weights(0), device=0, time_step=100)
 x0 = np.random.RandomState(0).randint(2, size=(B, 28, 28, 1)).astype(np.uint8)
-bitflip.diffusion_backward(x0[:64], model, 100, return_trajectory=False)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-out = bitflip.diffusion_backward(x0, model, 100, return_trajectory=False)
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
 flop = 199321600.0 * 100 * B     # conv MACs*2 of the improved UNet per forward x steps x images
-print(json.dumps({"workload": "mnist bit-flip sampler, 28x28, T=100, float32 canonical kernels", "images": B,
-                  "images_per_s": B / dt, "tflops": flop / dt / 1e12, "frac_of_fp32_mfma_peak": flop / dt / 157.3e12,
-                  "mean_final_pixel": float(out.float().mean())}))
+for precision, peak, label in (("fp32", 157.3e12, "frac_of_fp32_mfma_peak"), ("bf16", 2500e12, "frac_of_bf16_mfma_peak")):
+    model = bitflip.BitflipModel(bitflip.synthetic_weights(0), device=0, time_step=100, precision=precision)
+    bitflip.diffusion_backward(x0[:64], model, 100, return_trajectory=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = bitflip.diffusion_backward(x0, model, 100, return_trajectory=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"workload": f"mnist bit-flip sampler, 28x28, T=100, {precision} convolutions", "images": B,
+                      "images_per_s": B / dt, "tflops": flop / dt / 1e12, label: flop / dt / peak,
+                      "mean_final_pixel": float(out.float().mean())}))

@@ -331,3 +331,33 @@ def test_sample_philox_shard_independent(gpu_real):
     c = sample(gpu_real, 6, 20, T=T, betas=betas, seed=9, precision="fp32", keep_state=True, chunk=4)
     assert torch.equal(full.x_final, c.x_final)
     assert int(full.observables.moments[0]) == 6
+
+
+def test_full_size_batch_properties(gpu_real):
+    """The bench workload's batch (65 536 lattices, L=32, bf16 fused kernels, automatic chunking) on a short
+    slice of the schedule, checked through size-independent properties: a lattice's result depends only on
+    (seed, global index) - not on the batch, its chunk or its position in the persistent grid - and the
+    histograms and moments equal those recomputed from the spins."""
+    import torch
+    from isingdiff.sampler import sample, beta_schedule
+    n, L, T = 65536, 32, 3
+    betas = beta_schedule(1000)[:T]
+    full = sample(gpu_real, n, L, T=T, betas=betas, seed=11, precision="bf16", keep_state=True)
+    assert full.x_final.shape == (n, L, L, 1) and bool(torch.isfinite(full.x_final).all())
+    # windows around the chunk boundary (10 923 lattices per chunk), the ends and the middle
+    for g0, cnt in ((0, 5), (10920, 7), (32768, 3), (65531, 5)):
+        part = sample(gpu_real, cnt, L, T=T, betas=betas, seed=11, precision="bf16", keep_state=True, first_global_index=g0)
+        assert torch.equal(full.x_final[g0:g0 + cnt], part.x_final), g0
+        assert torch.equal(full.spins[g0:g0 + cnt], part.spins), g0
+    s = full.spins.to(torch.int32)
+    assert bool((s.abs() == 1).all())
+    M = s.sum((1, 2))
+    S = (s * torch.roll(s, -1, 1)).sum((1, 2)) + (s * torch.roll(s, -1, 2)).sum((1, 2))
+    obs = full.observables
+    assert torch.equal(obs.M.to(torch.int64), M.to(torch.int64)) and torch.equal(obs.S.to(torch.int64), S.to(torch.int64))
+    assert int(obs.hist_M.sum()) == n and int(obs.hist_S.sum()) == n
+    hM = torch.bincount(((M + L * L) // 2).to(torch.int64), minlength=L * L + 1)
+    assert torch.equal(obs.hist_M.to(torch.int64).cpu(), hM.cpu())
+    mom = [int(v) for v in obs.moments.cpu()]
+    assert mom == [n, int(M.sum()), int(M.abs().sum()), int((M.to(torch.int64) ** 2).sum()), int(S.sum()),
+                   int((S.to(torch.int64) ** 2).sum())]

@@ -42,3 +42,12 @@ DEVI void normal4(uint64_t seed, int64_t lattice, uint32_t quad, int32_t t, floa
     z[0] = m0 * c0; z[1] = m0 * s0; z[2] = m1 * c1; z[3] = m1 * s1;
 }
 
+// Reverse update x' = ((c1*x) + (beta*score)) + (z*sd): every product and sum rounded separately (no fused
+// multiply-add), whatever the translation unit's contraction setting - the same value in every kernel and build.
+DEVI float reverse_update(float c1, float x, float beta, float score, float z, float sd, bool add_noise)
+{
+#pragma clang fp contract(off)
+    float v = c1 * x + beta * score;
+    if (add_noise) v = v + z * sd;
+    return v;
+}

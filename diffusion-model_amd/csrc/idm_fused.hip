@@ -173,7 +173,7 @@ extern "C" int idm_debug_timeline(long long *host)
 #define TL(i) do { } while (0)
 #endif
 
-// Persistent: each workgroup walks bands wg = blockIdx.x, blockIdx.x + gridDim.x, ...
+// Persistent: each workgroup walks the bands of lattices blockIdx.x, blockIdx.x + gridDim.x, ...
 //
 // Vector-memory results return in issue order, so a wait for a weight fragment also waits for
 // every older load or store of the wavefront.  The loop is therefore arranged so that long-latency
@@ -199,14 +199,18 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
     constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16, SM = C1 * 2 + 16, SO = C2 * 2 + 16;
     constexpr int CAT = MODE1 == M1_FIRST ? 8 : CA, CBT = MODE1 == M1_UPCAT ? CB : 8;
     (void)SA; (void)SB; (void)SO;
-    // work items are indexed in 32 bits (the host checks B * nbands < 2^31); specialised instances know nbands
+    // A workgroup owns whole lattices (blockIdx.x, blockIdx.x + gridDim.x, ...) and walks each one's bands top
+    // to bottom: item n of a workgroup is band n % nbands of its (n / nbands)-th lattice.  The two bottom rows of
+    // the mid tile (conv1 at global rows y0+R-1, y0+R) are what the next band needs as its rows 0 and 1, so they
+    // are carried over in LDS and conv1 never computes a row twice.  Specialised instances know nbands.
     const int nbands = (WT && RT) ? WT / RT : a.nbands;
-    const int total = (int)a.B * nbands;
+    const int nlat = (int)a.B;
     struct Item { int b, y0; };
-    auto item_of = [&](int wg) {
+    auto item_of = [&](int n) {
         Item it;
-        it.b = wg / nbands;
-        it.y0 = (wg - it.b * nbands) * R;
+        const int q = n / nbands;
+        it.b = (int)blockIdx.x + q * (int)gridDim.x;
+        it.y0 = (n - q * nbands) * R;
         return it;
     };
 #ifdef IDM_TIMELINE
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
         int lane = threadIdx.x & 63;
         asm volatile("" : "+v"(lane));
         const int b = it.b, y0 = it.y0;
-        const int rlo = y0 == 0 ? 1 : 0, rhi = min(R + 2, H - y0 + 1);
+        const int rlo = y0 == 0 ? 1 : 2, rhi = min(R + 2, H - y0 + 1);   // as band_geo
         const int tot = Conv1::NSL * geo.ncb * ((rhi - rlo + geo.TR - 1) / geo.TR);
         int len[NW], mn = 1 << 30;
 #pragma unroll
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
         }
     };
     auto band_geo = [&](Item it, int &rlo, int &rhi) {
-        rlo = it.y0 == 0 ? 1 : 0;
+        rlo = it.y0 == 0 ? 1 : 2;   // mid row 0 of the top band is padding; rows 0, 1 of the others are carried over
         rhi = min(R + 2, H - it.y0 + 1);
     };
     auto conv1_begin = [&](Item it) {
@@ -353,15 +357,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
         clear_halo<CA, WGS>(tile_a, W >> 1, (R >> 1) + 2, 0, 0, tid);
         clear_halo<CB, WGS>(tile_b, W, R + 4, 0, 0, tid);
     }
-    int wg = blockIdx.x;
-    Item cur = item_of(wg < total ? wg : 0);
-    if (wg < total) {
+    Item cur = item_of(0);
+    if (cur.b < nlat) {
         conv1_begin(cur);
         x_fetch(cur);
         pf_load(cur);
     }
 
-    for (; wg < total; wg += gridDim.x) {
+    for (int n = 0; cur.b < nlat; ++n) {
         const int b = cur.b, y0 = cur.y0;
         int rlo, rhi;
         band_geo(cur, rlo, rhi);
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
         TL(9);
         pf_store();
         // rows of the mid tile outside the map are conv2's zero padding (an earlier band may have left data there)
-        if (rlo) clear_halo<C1, WGS>(lds_mid, W, 0, 0, 1, tid);
+        if (y0 == 0) clear_halo<C1, WGS>(lds_mid, W, 0, 0, 1, tid);
         if (rhi < R + 2) clear_halo<C1, WGS>(lds_mid, W, 0, rhi, R + 2, tid);
         TL(1);
         __syncthreads();
@@ -417,7 +420,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
         const int npix2 = rows2 * W;
         // the last iteration reloads its own band (discarded): an unconditional load keeps the prefetch
         // registers dead across the convolutions instead of loop-carried
-        const Item nxt = item_of(wg + (int)gridDim.x < total ? wg + (int)gridDim.x : wg);
+        const Item following = item_of(n + 1);
+        const Item nxt = following.b < nlat ? following : cur;
+        // rows R, R+1 of the mid tile become rows 0, 1 of the next band of this lattice (copied once conv2 is done)
+        auto carry_rows = [&] {
+            if (y0 + R < H) {
+                const int bytes = 2 * (W + 2) * SM;   // a multiple of 16
+                const char *src = lds_mid + R * (W + 2) * SM;
+                for (int i = tid * 16; i < bytes; i += WGS * 16) *(f32x4 *)(lds_mid + i) = *(const f32x4 *)(src + i);
+            }
+        };
         cs2.begin(lds_mid, nullptr, c_b2, c_wh, geo, 0, rows2, (const bf16x8 *)a.w2, wave, lane, 0, NW);
         if constexpr (EARLY_PF) {
             x_fetch(nxt);
@@ -447,6 +459,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
             }
             __syncthreads();
             TL(6);
+            carry_rows();
 
             const Quad q = quad_of(cur);
             if (q.path) {
@@ -463,9 +476,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
                         f32x4 xv = x_cur;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            float v = __fadd_rn(__fmul_rn(a.c1, xv[j]), __fmul_rn(a.beta, sc[j]));
-                            if (a.add_noise) v = __fadd_rn(v, __fmul_rn(z[j], a.sd));
-                            xv[j] = v;
+                            xv[j] = reverse_update(a.c1, xv[j], a.beta, sc[j], z[j], a.sd, a.add_noise != 0);
                         }
                         *(f32x4 *)(a.x + q.off) = xv;
                     }
@@ -489,9 +500,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
                             zz = z[e & 3];
                         }
                     }
-                    float v = __fadd_rn(__fmul_rn(a.c1, xg[e]), __fmul_rn(a.beta, sc));
-                    if (a.add_noise) v = __fadd_rn(v, __fmul_rn(zz, a.sd));
-                    xg[e] = v;
+                    xg[e] = reverse_update(a.c1, xg[e], a.beta, sc, zz, a.sd, a.add_noise != 0);
                 }
             }
         } else {
@@ -512,6 +521,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
             if constexpr (!EARLY_PF) pf_load(nxt);
             __syncthreads();
             TL(6);
+            carry_rows();
             constexpr int CH = C2 / 8;
             __bf16 *og = (__bf16 *)a.out + ((size_t)b * H + y0) * W * C2;
             for (int i = tid; i < npix2 * CH; i += WGS) {
@@ -538,7 +548,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
         TL(7);
         if constexpr (EPI2 != E2_HEAD) __syncthreads();  // staging consumed before the next band's input overwrites the region
         TL(8);
-        cur = nxt;
+        cur = following;
 #ifdef IDM_TIMELINE
         ++tl_it;
 #endif
@@ -644,7 +654,7 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
     }
     const int64_t total = B * a.nbands;
     if (total >= ((int64_t)1 << 31)) return hipErrorInvalidValue;   // the kernels index work items in 32 bits
-    const int64_t grid = std::min<int64_t>(total, (int64_t)st.cus * st.cached_blocks);
+    const int64_t grid = std::min<int64_t>(B, (int64_t)st.cus * st.cached_blocks);   // a workgroup owns whole lattices
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, s, a);
     return hipGetLastError();
 }

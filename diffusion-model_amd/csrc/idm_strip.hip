@@ -216,9 +216,7 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
                     f32x4 xv = x_cur;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float v = __fadd_rn(__fmul_rn(a.c1, xv[j]), __fmul_rn(a.beta, sc[j]));
-                        if (a.add_noise) v = __fadd_rn(v, __fmul_rn(z[j], a.sd));
-                        xv[j] = v;
+                        xv[j] = reverse_update(a.c1, xv[j], a.beta, sc[j], z[j], a.sd, a.add_noise != 0);
                     }
                     *(f32x4 *)(a.x + q.off) = xv;
                 }

@@ -361,3 +361,24 @@ def test_full_size_batch_properties(gpu_real):
     mom = [int(v) for v in obs.moments.cpu()]
     assert mom == [n, int(M.sum()), int(M.abs().sum()), int((M.to(torch.int64) ** 2).sum()), int(S.sum()),
                    int((S.to(torch.int64) ** 2).sum())]
+
+
+@pytest.mark.parametrize("L", [32, 64])
+def test_bf16_update_is_the_canonical_expression_of_its_score(gpu_real, L):
+    """One reverse step on the bf16 path (L=32: fused band kernels, L=64: strip kernels), injected noise: the new
+    state equals ((c1*x) + (beta*score)) + (z*sd) with every operation rounded to float32 separately, bit for bit,
+    for the score the same call returns (the update is fused into the last convolution kernel)."""
+    from isingdiff.sampler import diffusion_backward, beta_schedule
+    rs = np.random.RandomState(12)
+    B = 6
+    x = rs.standard_normal((B, L, L, 1)).astype(np.float32)
+    z = rs.standard_normal((1, B, L, L, 1)).astype(np.float32)
+    for beta in (beta_schedule(1000)[0], beta_schedule(1000)[999]):
+        betas = np.array([beta], np.float32)
+        traj, scores = diffusion_backward(x, betas, gpu_real, 1, noise=z, precision="bf16", return_scores=True)
+        new, sc = np.asarray(traj[0], np.float32), np.asarray(scores[0], np.float32)
+        c1 = np.float32(1.0) + np.float32(0.5) * beta
+        sd = np.sqrt(beta, dtype=np.float32)
+        want = (c1 * x + beta * sc) + z[0] * sd       # numpy float32: one rounding per operation
+        assert want.dtype == np.float32
+        assert np.array_equal(new.view(np.uint32), want.view(np.uint32))

@@ -32,9 +32,9 @@ PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA
 PEAK_FP32_TFLOPS = 157.3              # MI355X fp32 MFMA
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per lattice per launch of the dominant kernel at L=32 (x, skip1 and the conv7 map in,
-# x out), from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes kept in profiles/r01/v5_pmc_hbm.txt
+# x out), from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes kept in profiles/r01/v6_pmc_hbm.txt
 # (FETCH_SIZE doubled: gfx950 counts 16-byte-per-lane streaming reads at half their bytes).
-PMC_HBM_BYTES_PER_LATTICE = {"fused_B(conv8,9,head,step)": 140.1 * 1024}
+PMC_HBM_BYTES_PER_LATTICE = {"fused_B(conv8,9,head,step)": 106.3 * 1024}
 
 
 def cpu_baseline(spec, L, T, betas, budget_s=20.0):
@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel event timing")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=INT", help="library tuning switch (idm_set_option), e.g. strip_below_rows=0")
     args = ap.parse_args()
 
     if os.environ.get("ISINGDIFF_BENCH_TRACE"):      # debugging aid: dump every thread's stack after N seconds and exit
@@ -112,6 +113,9 @@ def main():
 
     path = os.path.join(ROOT, "weights", "b_diffusion_model_2d_ising_realspace_unet.keras")
     model = load_model(path, device=local_rank, precision=args.precision)
+    for opt in args.option:
+        name, _, val = opt.partition("=")
+        model.set_option(name, int(val))
     betas = beta_schedule(args.T)
     B, L, T = args.batch, args.L, args.T
     first = rank * B
@@ -168,7 +172,7 @@ def main():
                 lat_per_launch = B * args.steps * 1.0 / (dom["launches"] / T)
                 roof = {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                         "frac": ach / peak, "traffic": per_lat * lat_per_launch if per_lat else None,
-                        "traffic_unit": "HBM bytes per launch (PMC, profiles/r01/v5_pmc_hbm.txt)",
+                        "traffic_unit": "HBM bytes per launch (PMC, profiles/r01/v6_pmc_hbm.txt)",
                         "flop_per_launch": dom["flop"] / dom["launches"], "avg_launch_us": 1e3 * dom["ms"] / dom["launches"],
                         "share_of_gpu_time": dom["ms"] / tot_ms}
             else:

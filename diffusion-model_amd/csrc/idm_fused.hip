@@ -325,7 +325,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
         const int qrow = Wx >> 2, nq = max(rowsx, 0) * qrow;
         const int qpw = nl == 4 ? (nq + 3) >> 2 : nl == 2 ? (nq + 1) >> 1 : nl == 1 ? nq : nl == 3 ? (nq + 2) / 3
                       : nl == 8 ? (nq + 7) >> 3 : nl == 6 ? (nq + 5) / 6 : (nq + nl - 1) / nl;
-        q.path = WT ? true : ((Wx & 3) == 0 && qpw <= 64);
+        q.path = (Wx & 3) == 0 && qpw <= 64;   // one quad per lane of the light wavefronts, else the generic loop
         const int qi = lr * qpw + lane;
         q.act = q.path && mine && lane < qpw && qi < nq;
         const int qr = qi / max(qrow, 1), qx = qi - qr * qrow;
@@ -374,12 +374,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
         TL(0);
         TL(9);
         pf_store();
-        // rows of the mid tile outside the map are conv2's zero padding (an earlier band may have left data there)
-        if (y0 == 0) clear_halo<C1, WGS>(lds_mid, W, 0, 0, 1, tid);
-        if (rhi < R + 2) clear_halo<C1, WGS>(lds_mid, W, 0, rhi, R + 2, tid);
         TL(1);
         __syncthreads();
         TL(2);
+        // Rows of the mid tile outside the map are conv2's zero padding (an earlier band may have left data there).
+        // Cleared after the barrier: before it, a slower wavefront may still be copying the previous band's bottom
+        // rows (the carry-over), which are the rows cleared here in a lattice's last band; conv1's epilogue writes
+        // only rows inside the map, and conv2 reads after the next barrier.
+        if (y0 == 0) clear_halo<C1, WGS>(lds_mid, W, 0, 0, 1, tid);
+        if (rhi < R + 2) clear_halo<C1, WGS>(lds_mid, W, 0, rhi, R + 2, tid);
 
         // ---- conv1 on rows y0-1 .. y0+R (clipped to the map) -> mid tile row (g - (y0-1)) ----
         {

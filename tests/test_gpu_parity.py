@@ -97,7 +97,7 @@ def test_bf16_fused_matches_per_layer_kernels(gpu_real, B, H, W, t):
     assert e < BF16_SCORE_TOL, e
 
 
-@pytest.mark.parametrize("B,L,t", [(3, 32, 600), (2, 64, 800), (1, 128, 400)])
+@pytest.mark.parametrize("B,L,t", [(3, 32, 600), (2, 64, 800), (1, 128, 400), (3, 40, 500), (5, 48, 600), (2, 96, 700)])
 def test_bf16_strip_kernels_match_fused_and_per_layer(gpu_real, B, L, t):
     """Single-convolution strip kernels (used where a fused band would have to shrink) against the fused
     bands (forced where possible) and the per-layer kernels, layer by layer; also the in-kernel update."""

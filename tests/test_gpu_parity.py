@@ -349,6 +349,10 @@ def test_full_size_batch_properties(gpu_real):
         part = sample(gpu_real, cnt, L, T=T, betas=betas, seed=11, precision="bf16", keep_state=True, first_global_index=g0)
         assert torch.equal(full.x_final[g0:g0 + cnt], part.x_final), g0
         assert torch.equal(full.spins[g0:g0 + cnt], part.spins), g0
+    # batches smaller and larger than the persistent grid (512-768 workgroups), odd sizes
+    for cnt in (1, 257, 1000, 3001):
+        part = sample(gpu_real, cnt, L, T=T, betas=betas, seed=11, precision="bf16", keep_state=True)
+        assert torch.equal(full.x_final[:cnt], part.x_final), cnt
     s = full.spins.to(torch.int32)
     assert bool((s.abs() == 1).all())
     M = s.sum((1, 2))

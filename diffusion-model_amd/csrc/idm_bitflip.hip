@@ -91,15 +91,32 @@ __global__ __launch_bounds__(256) void bf_gn_stats_kernel(const float *__restric
     const int64_t b = wv >> 3;
     const int g = (int)(wv & 7), Cg = C >> 3, N = HW * Cg;
     const float *xb = x + (size_t)b * HW * C + g * Cg;
+    // element e = lane, lane + 64, ... of the group is (pixel e / Cg, channel e % Cg); the index pair is stepped
+    // instead of divided (same elements, same order: each lane still adds its elements one by one)
+    const int p0 = lane / Cg, j0 = lane - p0 * Cg, dp = 64 / Cg, dj = 64 - dp * Cg;
     float s = 0.0f;
-    for (int e = lane; e < N; e += 64) s = __fadd_rn(s, xb[(size_t)(e / Cg) * C + e % Cg]);
+    {
+        int p = p0, j = j0;
+#pragma unroll 4
+        for (int e = lane; e < N; e += 64) {
+            s = __fadd_rn(s, xb[(size_t)p * C + j]);
+            j += dj; p += dp;
+            if (j >= Cg) { j -= Cg; ++p; }
+        }
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s = __fadd_rn(s, __shfl_xor(s, off, 64));
     const float mean = __fdiv_rn(s, (float)N);
     float q = 0.0f;
-    for (int e = lane; e < N; e += 64) {
-        const float d = __fsub_rn(xb[(size_t)(e / Cg) * C + e % Cg], mean);
-        q = __fmaf_rn(d, d, q);
+    {
+        int p = p0, j = j0;
+#pragma unroll 4
+        for (int e = lane; e < N; e += 64) {
+            const float d = __fsub_rn(xb[(size_t)p * C + j], mean);
+            q = __fmaf_rn(d, d, q);
+            j += dj; p += dp;
+            if (j >= Cg) { j -= Cg; ++p; }
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) q = __fadd_rn(q, __shfl_xor(q, off, 64));
@@ -118,12 +135,23 @@ template <typename OutT>
 __global__ __launch_bounds__(256) void bf_gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ ab,
                                                           OutT *__restrict__ y, int64_t n, int HW, int C)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // four consecutive channels of one pixel per thread (C is a multiple of 4)
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
     const int c = (int)(i % C);
     const int64_t b = i / ((int64_t)HW * C);
-    const float a = ab[(b * C + c) * 2], sh = ab[(b * C + c) * 2 + 1];
-    y[i] = (OutT)csilu(__fadd_rn(__fmul_rn(x[i], a), sh));
+    const f32x4 xv = *(const f32x4 *)(x + i);
+    const float *abp = ab + (b * C + c) * 2;
+    const f32x4 ab0 = *(const f32x4 *)abp, ab1 = *(const f32x4 *)(abp + 4);   // (a, shift) pairs of channels c .. c+3
+    const float a[4] = {ab0[0], ab0[2], ab1[0], ab1[2]}, sh[4] = {ab0[1], ab0[3], ab1[1], ab1[3]};
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = csilu(__fadd_rn(__fmul_rn(xv[k], a[k]), sh[k]));
+    if constexpr (sizeof(OutT) == 4) {
+        *(f32x4 *)((float *)y + i) = f32x4{r[0], r[1], r[2], r[3]};
+    } else {
+        *(bf16x4 *)((__bf16 *)y + i) = bf16x4{(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]};
+    }
 }
 
 // out = (conv1x1(x) + bias) + h  (the ResBlock's projected shortcut, :188-192); w == nullptr: out = x + h.
@@ -161,13 +189,15 @@ __global__ __launch_bounds__(256) void bf_maxpool_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void bf_upcat_kernel(const float *__restrict__ up, const float *__restrict__ skip,
                                                        float *__restrict__ out, int64_t B, int H, int W, int Cu, int Cs)
 {
+    // four consecutive channels per thread (Cu and Cs are multiples of 4: a quad never straddles the two parts)
     const int C = Cu + Cs, Ho = 2 * H, Wo = 2 * W;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= B * Ho * Wo * C) return;
     const int c = (int)(i % C);
     const int x = (int)((i / C) % Wo), y = (int)((i / ((int64_t)C * Wo)) % Ho);
     const int64_t b = i / ((int64_t)C * Wo * Ho);
-    out[i] = c < Cu ? up[((b * H + (y >> 1)) * W + (x >> 1)) * Cu + c] : skip[((b * Ho + y) * Wo + x) * Cs + (c - Cu)];
+    const float *src = c < Cu ? up + ((b * H + (y >> 1)) * W + (x >> 1)) * Cu + c : skip + ((b * Ho + y) * Wo + x) * Cs + (c - Cu);
+    *(f32x4 *)(out + i) = *(const f32x4 *)src;
 }
 
 // Conv2D(1, kernel 1, sigmoid) (:236)
@@ -316,9 +346,9 @@ void gn_silu(const float *x, int64_t B, int HW, int C, const float *gamma, const
     hipLaunchKernelGGL(bf_gn_stats_kernel, dim3((unsigned)((B * 8 + 3) / 4)), dim3(256), 0, s, x, B, HW, C, gamma, beta, ab);
     const int64_t n = B * HW * C;
     if (half)
-        hipLaunchKernelGGL(bf_gn_apply_kernel<__bf16>, dim3(blocks(n)), dim3(256), 0, s, x, (const float *)ab, (__bf16 *)y, n, HW, C);
+        hipLaunchKernelGGL(bf_gn_apply_kernel<__bf16>, dim3(blocks(n / 4)), dim3(256), 0, s, x, (const float *)ab, (__bf16 *)y, n, HW, C);
     else
-        hipLaunchKernelGGL(bf_gn_apply_kernel<float>, dim3(blocks(n)), dim3(256), 0, s, x, (const float *)ab, y, n, HW, C);
+        hipLaunchKernelGGL(bf_gn_apply_kernel<float>, dim3(blocks(n / 4)), dim3(256), 0, s, x, (const float *)ab, y, n, HW, C);
 }
 
 // half: `in` holds bf16 and wpack bf16 fragments -> bf16 MFMA kernel (float32 accumulation and output)
@@ -379,10 +409,10 @@ int forward_chunk(idm_bitflip *m, const uint8_t *x, const float *tvec, float *pr
     resblock(m, 1, pl, Bc, H2, W2, tv[1], r1, ta, tbuf, ab, s);
     hipLaunchKernelGGL(bf_maxpool_kernel, dim3(blocks(Bc * hw * 4)), dim3(256), 0, s, (const float *)r1, pl, Bc, H2, W2, 64);
     resblock(m, 2, pl, Bc, H4, W4, tv[2], r2, ta, tbuf, ab, s);
-    hipLaunchKernelGGL(bf_upcat_kernel, dim3(blocks(Bc * hw * 48)), dim3(256), 0, s, (const float *)r2, (const float *)r1,
+    hipLaunchKernelGGL(bf_upcat_kernel, dim3(blocks(Bc * hw * 48 / 4)), dim3(256), 0, s, (const float *)r2, (const float *)r1,
                        cat, Bc, H4, W4, 128, 64);
     resblock(m, 3, cat, Bc, H2, W2, tv[3], d3, ta, tbuf, ab, s);
-    hipLaunchKernelGGL(bf_upcat_kernel, dim3(blocks(Bc * hw * 96)), dim3(256), 0, s, (const float *)d3, (const float *)r0,
+    hipLaunchKernelGGL(bf_upcat_kernel, dim3(blocks(Bc * hw * 96 / 4)), dim3(256), 0, s, (const float *)d3, (const float *)r0,
                        cat, Bc, H2, W2, 64, 32);
     resblock(m, 4, cat, Bc, H, W, tv[4], d4, ta, tbuf, ab, s);
     hipLaunchKernelGGL(bf_head_kernel, dim3(blocks(Bc * hw)), dim3(256), 0, s, (const float *)d4, m->t[T_OUT_W],

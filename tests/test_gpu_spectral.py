@@ -80,7 +80,7 @@ def test_fft_unet_sampler_fp32_bit_exact(gpu_fft, ref_fft):
     assert np.array_equal(spins, np.where(real > 0, 1, -1))
 
 
-@pytest.mark.parametrize("L", [4, 10, 20, 32, 64])
+@pytest.mark.parametrize("L", [4, 10, 20, 32, 64, 128])
 def test_irfft2_sign_matches_numpy(L):
     """numpy's axis order: complex ifft along axis 0, then C2R along axis 1 (which drops the imaginary
     parts of the k=0 and k=L/2 columns after the first pass).  Random spectra, non-Hermitian on purpose."""
@@ -99,6 +99,23 @@ def test_irfft2_sign_matches_numpy(L):
     f = np.fft.rfft2(s0, s=(L, L))
     back = irfft2_sign(torch.from_numpy(np.stack([f.real, f.imag], -1).astype(np.float32)).cuda()).cpu().numpy()
     assert np.array_equal(back, s0.astype(np.int8))
+
+
+@pytest.mark.parametrize("L", [4, 20, 32, 64, 128])
+def test_irfft2_sign_matches_reference_fixture(L):
+    """tests/golden/reference_ifft_L*.npz: outputs of the reference's own ising_ifft (b_fft.py:12-17) on random
+    half spectra, written in the build container by tests/golden/make_reference_fixtures.py."""
+    import os
+    import torch
+    from isingdiff.spectral import irfft2_sign
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"reference_ifft_L{L}.npz"))
+    want = g["ising_ifft"]
+    spins, real = irfft2_sign(torch.from_numpy(g["spectrum"]).cuda(), return_real=True)
+    assert np.abs(real.cpu().numpy() - want).max() < 1e-12 * max(1.0, np.abs(want).max())
+    assert np.array_equal(spins.cpu().numpy(), np.where(want > 0, 1, -1).astype(np.int8))
+    # forward fixture: ising_fft of +-1 lattices (b_fft.py:4-9) comes back as the same lattices
+    f = np.stack([g["ising_fft_re"], g["ising_fft_im"]], -1).astype(np.float32)
+    assert np.array_equal(irfft2_sign(torch.from_numpy(f).cuda()).cpu().numpy(), g["spins"])
 
 
 def test_spectral_sample_end_to_end(gpu_fft):

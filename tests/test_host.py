@@ -120,15 +120,37 @@ def test_shard_range_partitions():
         shard_range(4, 4, 4)
 
 
-def test_onsager_known_answers():
-    """Values obtained from the reference's onsager.py (scipy ellipk/ellipe)."""
+def test_onsager_matches_reference_outputs():
+    """tests/golden/reference_onsager.npz holds outputs of the reference's own onsager.py:7-50 (scipy
+    ellipk / ellipe) on a kT grid, written by tests/golden/make_reference_fixtures.py."""
     from isingdiff import onsager_energy, onsager_heat_capacity, onsager_magnetization
-    for kT, e in ((2.0, -1.7455645753), (2.5, -1.1060792037), (2.2691, -1.4146594891), (1.5, -1.9511165731),
-                  (3.0, -0.8173095925)):
-        assert abs(onsager_energy(kT, 1.0) - e) < 1e-9
-    assert abs(onsager_magnetization(2.0, 1.0) - 0.9113193779) < 1e-9
+    from isingdiff.onsager import theoretical_critical_kT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_onsager.npz"))
+    assert float(g["critical_kT"]) == theoretical_critical_kT
+    for tag, J in (("J1", 1.0), ("J05", 0.5)):
+        for i, kT in enumerate(g["kT"]):
+            e, m, c = g[f"energy_{tag}"][i], g[f"magnetization_{tag}"][i], g[f"heat_capacity_{tag}"][i]
+            # K(m) is ill-conditioned as m = k^2 -> 1 (kT -> kT_c, where 1 - m ~ 1e-9 on this grid): away from
+            # kT_c the two implementations agree to 1e-15, at kT = 2.2691 to 3e-12 (energy) / 1e-8 (heat capacity)
+            assert abs(onsager_energy(float(kT), J) - e) <= 1e-11 * max(1.0, abs(e)), (tag, kT)
+            assert abs(onsager_magnetization(float(kT), J) - m) <= 1e-12, (tag, kT)
+            assert abs(onsager_heat_capacity(float(kT), J) - c) <= 1e-7 * max(1.0, abs(c)), (tag, kT)
     assert onsager_magnetization(2.5, 1.0) == 0.0
-    assert abs(onsager_heat_capacity(2.0, 1.0) - 2.8994857944) < 1e-8
+    assert abs(onsager_energy(2.0, 1.0) + 1.7455645753) < 1e-9   # the value the reference script prints at kT = 2
+
+
+def test_reference_ifft_fixtures_are_consistent():
+    """The committed b_fft.py outputs: ising_ifft is numpy's irfft2 of the stored spectra, ising_fft the
+    rfft2 of the stored lattices (guards the fixtures themselves; the GPU kernel is checked against them
+    in test_gpu_spectral.py)."""
+    for L in (4, 20, 32, 64, 128):
+        g = np.load(os.path.join(ROOT, "tests", "golden", f"reference_ifft_L{L}.npz"))
+        spec = g["spectrum"]
+        assert spec.shape[1:] == (L, L // 2 + 1, 2) and spec.dtype == np.float32
+        z = spec[..., 0].astype(np.float64) + 1j * spec[..., 1].astype(np.float64)
+        assert np.allclose(np.fft.irfft2(z, s=(L, L)), g["ising_ifft"], rtol=0, atol=1e-13)
+        f = np.fft.rfft2(g["spins"], s=(L, L))
+        assert np.allclose(f.real, g["ising_fft_re"], rtol=0, atol=1e-10) and np.allclose(f.imag, g["ising_fft_im"], rtol=0, atol=1e-10)
 
 
 def test_gpu_only_entry_points_fail_loudly_without_a_gpu(real_spec):

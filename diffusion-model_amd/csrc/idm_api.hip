@@ -127,8 +127,9 @@ struct idm_model {
     float *ttable = nullptr;
     int ttable_T = 0;
     float *trow = nullptr;                 // time-embedding row for an arbitrary t_norm
-    char *ws = nullptr;                    // activation workspace
+    char *ws = nullptr;                    // activation workspace owned by the handle (grow-only)
     size_t ws_bytes = 0;
+    char *ws_active = nullptr;             // workspace of the call in progress: ws, or the device's static scratch array
     std::vector<void *> owned;
     // profiling (idm_profile_begin/end)
     bool profiling = false;
@@ -213,21 +214,7 @@ Plan make_plan(const idm_model *m, int H, int W, int precision)
     p.Hp = H + (4 - H % 4) % 4;
     p.Wp = W + (4 - W % 4) % 4;
     p.es = precision == IDM_BF16 ? 2 : 4;
-    const size_t n1 = (size_t)p.Hp * p.Wp, n2 = n1 / 4, n4 = n1 / 16, F = m->F;
-    size_t o = 0;
-    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
-    p.off_a0 = take(n1 * F * p.es);
-    p.off_s1 = take(n1 * F * p.es);
-    p.off_a2 = take(n2 * 2 * F * p.es);
-    p.off_s2 = take(n2 * 2 * F * p.es);
-    p.off_a4 = take(n4 * 4 * F * p.es);
-    p.off_a5 = take(n4 * 4 * F * p.es);
-    p.off_a6 = take(n2 * 2 * F * p.es);
-    p.off_a7 = take(n2 * 2 * F * p.es);
-    p.off_a8 = take(n1 * F * p.es);
-    p.off_a9 = take(n1 * F * 4);
-    p.off_score = take((size_t)H * W * m->C * 4);
-    p.per_lattice = o;
+    for (int k = 0; k < 5; ++k) { p.R[k] = 0; p.strip[k] = false; }
     // the fused band kernels cover the real-space model (one state channel, no BatchNorm)
     p.fused = precision == IDM_BF16 && m->C == 1 && !m->bn && m->use_fused && m->w_first_pack != nullptr;
     if (p.fused) {
@@ -261,16 +248,54 @@ Plan make_plan(const idm_model *m, int H, int W, int precision)
             if (p.sR[sk] == 0) p.layers = false;
         }
     }
+    // Workspace: one buffer per kind, sized for what the selected schedule stores in it.  The fused schedule
+    // keeps only the maps that cross a kernel boundary (skip1 and its pool, skip2 and its pool, conv5, conv7:
+    // 172 KB per lattice at L = 32 in bf16), plus one intermediate per pair of layers that runs as strips.
+    const size_t n1 = (size_t)p.Hp * p.Wp, n2 = n1 / 4, n4 = n1 / 16, F = m->F;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    if (p.fused) {
+        p.off_a0 = take(n2 * F * p.es);                                                   // pooled skip1
+        p.off_s1 = take(n1 * F * p.es);
+        p.off_a2 = take(n4 * 2 * F * p.es);                                               // pooled skip2
+        p.off_s2 = take(n2 * 2 * F * p.es);
+        p.off_a4 = take(p.strip[FK_M2] ? n4 * 4 * F * p.es : 0);                          // conv4 between strips
+        p.off_a5 = take(n4 * 4 * F * p.es);
+        p.off_a6 = take(p.strip[FK_M1] || p.strip[FK_M3] ? n2 * 2 * F * p.es : 0);        // conv2 / conv6 between strips
+        p.off_a7 = take(n2 * 2 * F * p.es);
+        p.off_a8 = take(p.strip[FK_B] ? n1 * F * p.es : 0);                               // conv8 between strips
+        p.off_a9 = take(0);
+    } else {
+        p.off_a0 = take(n1 * F * p.es);
+        p.off_s1 = take(n1 * F * p.es);
+        p.off_a2 = take(n2 * 2 * F * p.es);
+        p.off_s2 = take(n2 * 2 * F * p.es);
+        p.off_a4 = take(n4 * 4 * F * p.es);
+        p.off_a5 = take(n4 * 4 * F * p.es);
+        p.off_a6 = take(n2 * 2 * F * p.es);
+        p.off_a7 = take(n2 * 2 * F * p.es);
+        p.off_a8 = take(n1 * F * p.es);
+        p.off_a9 = take(n1 * F * 4);
+    }
+    p.off_score = take((size_t)H * W * m->C * 4);
+    p.per_lattice = o;
     return p;
 }
 
 int ensure_ws(idm_model *m, size_t bytes)
 {
+    m->ws_active = m->ws;
     if (m->ws_bytes >= bytes) return IDM_OK;
-    if (m->ws) { HIPCHK(hipFree(m->ws)); m->ws = nullptr; m->ws_bytes = 0; }
+    if (m->ws) {
+        // work enqueued through this handle may still read the old workspace
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipFree(m->ws));
+        m->ws = nullptr; m->ws_bytes = 0; m->ws_active = nullptr;
+    }
     hipError_t e = hipMalloc((void **)&m->ws, bytes);
     if (e != hipSuccess) return fail(IDM_ERR_NOMEM, "workspace allocation of " + std::to_string(bytes) + " bytes failed");
     m->ws_bytes = bytes;
+    m->ws_active = m->ws;
     return IDM_OK;
 }
 
@@ -319,19 +344,22 @@ void timed(idm_model *m, const char *name, double flop, double bytes, hipStream_
     m->spans.push_back(sp);
 }
 
-int64_t auto_chunk(const Plan &p, int64_t B)
+// Lattices per chunk: the fewest equal chunks whose activation workspace stays within `budget` bytes
+// (equal, so that every launch of a kernel class does the same work).
+int64_t auto_chunk(const Plan &p, int64_t B, size_t budget = (size_t)6 << 30)
 {
-    const size_t budget = (size_t)6 << 30;  // keep the activation workspace around 6 GiB
-    int64_t c = (int64_t)std::max<size_t>(1, budget / p.per_lattice);
-    return std::min<int64_t>(B, c);
+    const int64_t cmax = (int64_t)std::max<size_t>(1, budget / p.per_lattice);
+    if (B <= cmax) return B;
+    const int64_t nchunks = (B + cmax - 1) / cmax;
+    return (B + nchunks - 1) / nchunks;
 }
 
-// Forward for `Bc` lattices whose workspace starts at m->ws.  Buffers of one kind are contiguous
+// Forward for `Bc` lattices whose workspace starts at m->ws_active.  Buffers of one kind are contiguous
 // over the chunk: base + off_kind*Bc.
 int forward_fused(idm_model *m, const Plan &p, const float *x, const float *tadd, float *score, int64_t Bc,
                   const StepCtx &ctx, float *const *taps, int64_t tap_b0, hipStream_t s)
 {
-    char *ws = m->ws;
+    char *ws = m->ws_active;
     auto buf = [&](size_t off) { return (void *)(ws + off * (size_t)Bc); };
     void *s1 = buf(p.off_s1), *p1 = buf(p.off_a0), *s2 = buf(p.off_s2), *p2 = buf(p.off_a2), *a5 = buf(p.off_a5),
          *a7 = buf(p.off_a7);
@@ -458,7 +486,7 @@ int forward_fused(idm_model *m, const Plan &p, const float *x, const float *tadd
 int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd, float *score, int64_t Bc,
                   int precision, float *const *taps, int64_t tap_b0, hipStream_t s)
 {
-    char *ws = m->ws;
+    char *ws = m->ws_active;
     auto buf = [&](size_t off) { return (void *)(ws + off * (size_t)Bc); };
     void *a0 = buf(p.off_a0), *s1 = buf(p.off_s1), *a2 = buf(p.off_a2), *s2 = buf(p.off_s2), *a4 = buf(p.off_a4),
          *a5 = buf(p.off_a5), *a6 = buf(p.off_a6), *a7 = buf(p.off_a7), *a8 = buf(p.off_a8);
@@ -730,7 +758,7 @@ int idm_sample(idm_model *m, const idm_sample_cfg *cfg, float *x_dev, const floa
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int64_t bc = std::min(chunk, B - b0);
         float *x = x_dev + b0 * elems;
-        float *score_ws = (float *)(m->ws + p.off_score * (size_t)bc);
+        float *score_ws = (float *)(m->ws_active + p.off_score * (size_t)bc);
         PhiloxArgs ph;
         ph.seed = cfg->seed;
         ph.first_global_index = cfg->first_global_index + b0;

@@ -87,6 +87,15 @@ std::vector<uint16_t> pack_first_bf16(const float *w, int cout)
 
 }  // namespace
 
+// Static workspace of idm_forward_noalloc: lives in the code object, one copy per GPU the library runs on,
+// held until the process ends.  In host code the array's name is only a handle for hipGetSymbolAddress; the
+// device address is looked up once per device (idm_model_create, with that device current) and kept here.
+static __device__ __align__(256) unsigned char scratch[IDM_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+char *g_scratch_ptr[IDM_MAX_DEVICES] = {};
+}
+
 int idm_set_error(int code, const char *msg) { return fail(code, msg ? msg : ""); }
 
 std::vector<float> idm_pack_weights_f32(const float *w, int cin, int cout) { return pack_weights_f32(w, cin, cout); }
@@ -614,6 +623,13 @@ int idm_model_create(idm_model **out, int device, const idm_model_desc *d)
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return fail(IDM_ERR_UNSUPPORTED, std::string("built for gfx950 (MI355X); device is ") + prop.gcnArchName);
 
+    if (device >= IDM_MAX_DEVICES) return fail(IDM_ERR_UNSUPPORTED, "device index beyond IDM_MAX_DEVICES");
+    if (!g_scratch_ptr[device]) {
+        void *ptr = nullptr;
+        HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[device] = (char *)ptr;
+    }
+
     idm_model *m = new idm_model();
     m->device = device; m->C = d->channels; m->F = d->base_filters; m->bn = d->batchnorm != 0;
     const int f = m->F, c = m->C;
@@ -731,6 +747,38 @@ int idm_forward(idm_model *m, const float *x_dev, float t_norm, float *score_dev
                 int precision, void *stream)
 {
     return idm_forward_taps(m, x_dev, t_norm, score_dev, B, H, W, precision, nullptr, stream);
+}
+
+int idm_forward_noalloc(idm_model *m, const float *x_dev, float t_norm, float *score_dev, int64_t B, int H, int W,
+                        int precision, void *stream)
+{
+    int rc = check_shape(m, B, H, W, precision);
+    if (rc != IDM_OK) return rc;
+    if (!x_dev || !score_dev) return fail(IDM_ERR_INVALID, "null tensor");
+    HIPCHK(hipSetDevice(m->device));
+    char *ws = g_scratch_ptr[m->device];
+    if (!ws) return fail(IDM_ERR_HIP, "static scratch address was not resolved for this device");
+    const Plan p = make_plan(m, H, W, precision);
+    if (p.per_lattice * (size_t)B > (size_t)IDM_NOALLOC_SCRATCH_BYTES)
+        return fail(IDM_ERR_INVALID, "idm_forward_noalloc: " + std::to_string(B) + " lattices of " + std::to_string(H) + "x" +
+                                         std::to_string(W) + " need " + std::to_string(p.per_lattice * (size_t)B) +
+                                         " bytes of workspace; the static scratch holds " +
+                                         std::to_string((size_t)IDM_NOALLOC_SCRATCH_BYTES) + " (at most " +
+                                         std::to_string((size_t)IDM_NOALLOC_SCRATCH_BYTES / p.per_lattice) +
+                                         " lattices of this shape and precision per call)");
+    hipStream_t s = (hipStream_t)stream;
+    // No event bracketing here (events are created on demand), and every buffer of the workspace is written
+    // before it is read, so nothing has to be cleared between calls.
+    const bool was_profiling = m->profiling;
+    m->profiling = false;
+    m->ws_active = ws;
+    launch_time_row(t_norm, 4 * m->F, m->dense_w[0], m->dense_b[0], m->dense_w[1], m->dense_b[1], m->dense_w[2],
+                    m->dense_b[2], m->trow, s);
+    if (p.fused) rc = forward_fused(m, p, x_dev, m->trow, score_dev, B, StepCtx(), nullptr, 0, s);
+    else rc = forward_chunk(m, p, x_dev, m->trow, score_dev, B, precision, nullptr, 0, s);
+    m->ws_active = m->ws;
+    m->profiling = was_profiling;
+    return rc;
 }
 
 int idm_sample(idm_model *m, const idm_sample_cfg *cfg, float *x_dev, const float *noise_dev, float *traj_dev,

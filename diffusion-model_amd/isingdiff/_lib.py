@@ -16,6 +16,7 @@ IDM_BF16 = 1
 NCONV = 11
 NDENSE = 3
 ABI_VERSION = 1
+NOALLOC_SCRATCH_BYTES = 64 << 20
 
 
 class IdmError(RuntimeError):
@@ -73,6 +74,7 @@ SIGNATURES = {
     "idm_model_destroy": (C.c_int, [C.c_void_p]),
     "idm_time_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "idm_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "idm_forward_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "idm_forward_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                    C.POINTER(C.c_void_p), C.c_void_p]),
     "idm_sample": (C.c_int, [C.c_void_p, C.POINTER(SampleCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

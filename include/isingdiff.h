@@ -100,6 +100,18 @@ int idm_time_table(idm_model *m, int T, float *table_host);
 int idm_forward(idm_model *m, const float *x_dev, float t_norm, float *score_dev,
                 int64_t B, int H, int W, int precision, void *stream);
 
+/* idm_forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as
+ * idm_forward, bit for bit, but the activation workspace is a static device array of
+ * IDM_NOALLOC_SCRATCH_BYTES that each GPU holds from library load until the process ends: the call performs
+ * no hipMalloc / hipFree.  A batch whose workspace exceeds the array is rejected with IDM_ERR_INVALID (the
+ * message states the largest B for that shape and precision; e.g. 390 lattices at L = 32 in bf16, 173 at
+ * L = 20 in float32).  All handles on one GPU share the array: calls that overlap on one GPU (different
+ * streams or threads) race; order them on one stream.  Per-kernel profiling is not recorded for these calls. */
+#define IDM_NOALLOC_SCRATCH_BYTES (64u << 20)
+int idm_forward_noalloc(idm_model *m, const float *x_dev, float t_norm, float *score_dev,
+                        int64_t B, int H, int W, int precision, void *stream);
+
 /* Optional taps for tests: like idm_forward, and copies layer i's activation (padded size,
  * float32, (B,h_i,w_i,c_i)) to taps_dev[i] for every non-NULL entry, i = 0..10. */
 int idm_forward_taps(idm_model *m, const float *x_dev, float t_norm, float *score_dev,

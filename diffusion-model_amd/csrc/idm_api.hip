@@ -887,9 +887,14 @@ int idm_irfft2_sign(int device, const float *spec_dev, int64_t B, int L, int8_t 
 {
     if (!spec_dev || !spins_dev || B <= 0) return fail(IDM_ERR_INVALID, "bad argument");
     if (L < 2 || (L & 1)) return fail(IDM_ERR_UNSUPPORTED, "irfft2 needs an even lattice size");
-    if ((size_t)(2 * L + 4 * L * (L / 2 + 1)) * sizeof(double) > 160 * 1024)
-        return fail(IDM_ERR_UNSUPPORTED, "lattice too large for the LDS-resident transform (L <= 98 in float64)");
     HIPCHK(hipSetDevice(device));
+    if (idm_fft_supported(L)) {
+        HIPCHK(launch_irfft2_fft(spec_dev, B, L, spins_dev, real_dev, (hipStream_t)stream));
+        return IDM_OK;
+    }
+    // other even sizes: direct sums over a twiddle table (O(L^3) per lattice)
+    if ((size_t)(2 * L + 4 * L * (L / 2 + 1)) * sizeof(double) > 160 * 1024)
+        return fail(IDM_ERR_UNSUPPORTED, "no FFT instance for this lattice size, and it is too large for the direct-sum transform (L <= 98)");
     HIPCHK(launch_irfft2_sign(spec_dev, B, L, spins_dev, real_dev, (hipStream_t)stream));
     return IDM_OK;
 }

@@ -24,7 +24,9 @@ DEVI void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-DEVI float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * 5.9604644775390625e-08f; }  // (0,1), exact
+// Uniform in (0,1) from the top 23 bits: (k + 1/2) * 2^-23 with k < 2^23 is exactly representable in float32
+// (24 significant bits), so the value never rounds to 0 or 1 and every step of the grid is equally likely.
+DEVI float u01(uint32_t r) { return ((float)(r >> 9) + 0.5f) * 1.1920928955078125e-07f; }
 
 DEVI void normal4(uint64_t seed, int64_t lattice, uint32_t quad, int32_t t, float z[4])
 {

@@ -1,10 +1,29 @@
 // Fused two-convolution band kernels (bf16 MFMA, float32 accumulate).
 //
-// One workgroup (4 wavefronts) owns one band of R output rows of one lattice and runs
-//     stage-in -> conv1 -> (LDS) -> conv2 -> epilogue
-// without the intermediate map ever leaving the CU.  conv1 is evaluated on R+2 rows (one halo
-// row each side, recomputed by the neighbouring band) so that conv2 sees exactly the zero-padded
-// "same" convolution of the whole map.  The UNet's data movement is folded into the edges:
+// A persistent workgroup owns whole lattices and walks each one's bands of R output rows top to bottom:
+//     copy-in -> conv1 -> mid tile (LDS) -> conv2 -> epilogue / copy-out
+// so the intermediate map never leaves the CU.  conv2 on rows y0 .. y0+R-1 needs conv1 on rows y0-1 .. y0+R
+// (mid tile rows 0 .. R+1).  Its two bottom rows are the next band's rows 0 and 1: they are CARRIED OVER in
+// LDS (copied to the top of the mid tile once conv2 has read them), so conv1 computes every row of the map
+// exactly once (rows y0+1 .. y0+R per band, one more in a lattice's top band) and nothing is recomputed.
+//
+// Barriers per band (B1..B4; HEAD kernels have no B4) and what each phase touches:
+//     [prefetched input registers -> input tiles]                      writes: input tiles
+//  B1 the input tiles are complete; the previous band's carry copy (all wavefronts) is done
+//     clear the mid rows that lie outside the map (top band: row 0; last band: rows below the map) - AFTER B1,
+//     because in a lattice's last band those are the very rows the previous band's carry copy wrote
+//     conv1                                                            reads: input tiles; writes: mid rows inside the map
+//  B2 the mid tile is complete
+//     conv2                                                            reads: mid tile; writes: staging tile (= input region) / score tile
+//  B3 conv2 has read every mid row; staging / score tile complete
+//     carry rows R, R+1 -> rows 0, 1; copy-out / head + state update    reads: mid rows R, R+1, staging / score tile
+//  B4 (store kernels) the staging tile, which aliases the input region, has been read before the next copy-in.
+//     HEAD keeps its score tile apart from the input tiles, so its next copy-in needs no barrier: the carry copy
+//     and the next band's clears are ordered by the next B1.
+// Moving a clear ahead of B1, or the carry copy ahead of B3, is a race that shows only as rare wrong bits; the
+// batch-composition property test (a lattice's result does not depend on which workgroup ran it) guards it.
+//
+// The UNet's data movement is folded into the edges:
 //     FIRST   conv1 reads the float32 state x (Cin = 1, the 9 taps are the K of one MFMA step,
 //             x split into bf16 hi + lo so the state keeps ~16 mantissa bits)
 //     UPCAT   conv1 reads Concatenate([UpSampling2D(a), skip]): nearest upsampling is an index

@@ -76,6 +76,9 @@ void launch_sign_project(const float *x, int8_t *spins, int64_t n, hipStream_t s
 void launch_observe(const int8_t *spins, int64_t B, int L, int32_t *M, int32_t *S, unsigned long long *histM,
                     unsigned long long *histS, long long *moments, hipStream_t s);
 hipError_t launch_irfft2_sign(const float *spec, int64_t B, int L, int8_t *spins, double *real_out, hipStream_t s);
+// in-register FFT instances of the same transform (idm_fft.hip) for the lattice sizes idm_fft_supported() names
+bool idm_fft_supported(int L);
+hipError_t launch_irfft2_fft(const float *spec, int64_t B, int L, int8_t *spins, double *real_out, hipStream_t s);
 void launch_metropolis(int8_t *spins, int64_t B, int L, const float *table10, int n_sweeps, const PhiloxArgs &ph, int sweep0,
                        hipStream_t s);
 void launch_cast_bf16_to_f32(const void *in, float *out, int64_t n, hipStream_t s);

@@ -61,12 +61,27 @@ def synthetic_weights(seed: int = 0) -> dict:
     return out
 
 
-def sinusoidal_table(time_step: int, dim: int = EMB_DIM, max_positions: int = 10000) -> np.ndarray:
+TIME_INPUTS = ("float", "int64")
+
+
+def sinusoidal_table(time_step: int, dim: int = EMB_DIM, max_positions: int = 10000, time_input: str = "float") -> np.ndarray:
     """Rows t = 0..time_step-1 of SinusoidalPositionalEmbedding (``:67-99``) evaluated at the
     sampler's input ``float32(t) / float32(time_step)`` (``:47``), in float32:
-    ``freqs = exp(-log(max_positions) * arange(half) / (half - 1))``, ``[cos(args) | sin(args)]``."""
+    ``freqs = exp(-log(max_positions) * arange(half) / (half - 1))``, ``[cos(args) | sin(args)]``.
+
+    ``time_input`` settles an ambiguity of the reference that cannot be resolved without running Keras: the model
+    declares ``time_input = Input(shape=(), dtype=tf.int64)`` (``:197``) but the sampler feeds ``float32(t / time_step)``
+    in [0, 1) (``:47``).  ``"float"`` (default) embeds the float value, which is what the layer's own
+    ``tf.cast(inputs, tf.float32)`` (``:79``) and the training loop's inputs suggest was meant; ``"int64"`` applies the
+    cast to the declared input dtype first, as a Keras functional model does when it standardises its inputs: every
+    step then sees position int64(t / time_step) = 0 and the model loses its time dependence.  Parity with Keras is
+    unpinned either way (no weights, no recorded outputs, Keras not importable)."""
+    if time_input not in TIME_INPUTS:
+        raise ValueError(f"time_input must be one of {TIME_INPUTS}")
     half = dim // 2
     pos = (np.arange(time_step, dtype=np.float32) / np.float32(time_step)).astype(np.float32)
+    if time_input == "int64":
+        pos = pos.astype(np.int64).astype(np.float32)      # truncation toward zero, then the layer's cast to float32
     freqs = np.exp((np.float32(-np.log(np.float32(max_positions))) * np.arange(half, dtype=np.float32)
                     / np.float32(half - 1)).astype(np.float32)).astype(np.float32)
     args = (pos[:, None] * freqs[None, :]).astype(np.float32)
@@ -84,7 +99,8 @@ class BitflipModel:
     """``model([X, t_tensor])`` of the reference (``:48``): X (B,H,W,1) bool / 0-1, t_tensor (B,) with one
     shared value ``t / time_step``; returns the flip probabilities (B,H,W,1) float32 (torch, on the GPU)."""
 
-    def __init__(self, weights: dict, device: int = 0, time_step: int = 100, precision: str = "fp32"):
+    def __init__(self, weights: dict, device: int = 0, time_step: int = 100, precision: str = "fp32",
+                 time_input: str = "float"):
         import torch
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
@@ -105,7 +121,8 @@ class BitflipModel:
             else:
                 desc.tensors[i] = None
         self._keep = keep
-        self._emb = sinusoidal_table(time_step)
+        self.time_input = time_input
+        self._emb = sinusoidal_table(time_step, time_input=time_input)
         h = C.c_void_p()
         with torch.cuda.device(device):
             _lib.check(_lib.load().idm_bitflip_create(C.byref(h), device, C.byref(desc)))

@@ -135,7 +135,12 @@ def diffusion_backward(x_asym, beta_lst, score_model: DenseScoreModel, T: int, *
     torch = score_model.torch
     x = score_model._f32(x_asym).clone()
     B, n = x.shape
-    betas = np.ascontiguousarray(np.asarray(beta_lst.cpu() if torch.is_tensor(beta_lst) else beta_lst, np.float32)[:T])
+    betas = np.ascontiguousarray(np.asarray(beta_lst.cpu() if torch.is_tensor(beta_lst) else beta_lst, np.float32).reshape(-1))
+    if T <= 0 or betas.shape[0] < T:
+        raise ValueError(f"beta_lst must have at least T={T} entries (the library reads betas[0..T-1])")
+    betas = np.ascontiguousarray(betas[:T])
+    if x.dim() != 2 or n != score_model.n:
+        raise ValueError(f"x_asym must be (B, {score_model.n})")
     z = None
     if noise is not None and noise is not False:
         z = score_model._f32(noise)

@@ -105,8 +105,12 @@ def sample(model: ScoreModel, n: int, L: int, *, T: int = 1000, betas=None, seed
         init = True
     else:
         x = torch.as_tensor(x_T, dtype=torch.float32).to(model.device).clone().contiguous()
+        if tuple(x.shape) != shape:
+            raise ValueError(f"x_T must have shape {shape}, got {tuple(x.shape)}")
         init = False
     z = None if noise is None else torch.as_tensor(noise, dtype=torch.float32).to(model.device).contiguous()
+    if z is not None and tuple(z.shape) != (T,) + shape:
+        raise ValueError(f"noise must have shape {(T,) + shape}, got {tuple(z.shape)}")
     spins = torch.empty(shape, dtype=torch.int8, device=model.device)
     if n > 0:
         _run(model, x, betas, T, noise=z, traj=None, scores=None, spins=spins, precision=prec, seed=seed,

@@ -213,7 +213,11 @@ typedef struct {
 typedef struct {
     int32_t T;                     /* time_step; t runs T-1 .. 0 */
     int32_t reserved;
-    const float *emb_table_host;   /* (T, 32): SinusoidalPositionalEmbedding (:67-99) of float32(t)/float32(T) */
+    const float *emb_table_host;   /* (T, 32): SinusoidalPositionalEmbedding (:67-99), row t = embedding of the value the
+                                      model sees at step t.  The sampler feeds float32(t)/float32(T) (:47) to an Input
+                                      declared int64 (:197): pass the rows of that float (what this library's Python
+                                      binding does by default) or, if Keras casts to the declared dtype first, T copies
+                                      of the row of position 0.  Parity with Keras is unpinned on this point. */
     uint64_t seed;                 /* Philox key for the uniforms (used when uniforms_dev == NULL) */
     int64_t first_global_index;    /* global index of sample 0 (uniforms do not depend on sharding) */
     int64_t chunk;                 /* samples processed together; 0 = automatic */

@@ -11,7 +11,7 @@
  *
  * Definition shared with the kernel: colour c of sweep w updates the sites with (row + col) % 2 == c;
  * the k-th such site in row-major order draws component k % 4 of Philox4x32-10 with counter
- * (k / 4, chain lo, chain hi, 2*w + c) and the seed as key, u = ((r >> 8) + 0.5) * 2^-24; it flips
+ * (k / 4, chain lo, chain hi, 2*w + c) and the seed as key, u = ((r >> 9) + 0.5) * 2^-23; it flips
  * when u < table[(s+1)/2][(nn+4)/2], the float32 acceptance table built by the caller.
  */
 #include <stdint.h>
@@ -34,7 +34,7 @@ void ref_metropolis(int8_t *spins, int B, int L, const float *table /* [2][5] */
                     const int r = k / half, col = 2 * (k % half) + ((r + c) & 1);
                     uint32_t ctr[4] = {(uint32_t)(k >> 2), (uint32_t)g, (uint32_t)((uint64_t)g >> 32), (uint32_t)(2 * w + c)}, out[4];
                     ref_philox4x32(ctr, key, out);
-                    const float u = ((float)(out[k & 3] >> 8) + 0.5f) * 5.9604644775390625e-08f;
+                    const float u = ((float)(out[k & 3] >> 9) + 0.5f) * 1.1920928955078125e-07f;
                     const int s = x[r * L + col];
                     const int nn = x[((r + 1) % L) * L + col] + x[((r + L - 1) % L) * L + col] + x[r * L + (col + 1) % L] +
                                    x[r * L + (col + L - 1) % L];

@@ -39,6 +39,17 @@ def test_sinusoidal_table():
     assert abs(emb[37, 15] - np.cos(t * 1e-4)) < 1e-6 and abs(emb[37, 31] - np.sin(t * 1e-4)) < 1e-6
 
 
+def test_sinusoidal_table_int64_input_cast():
+    """time_input="int64": the declared Input dtype (mnist_diffusion.py:197) applied to float32(t / time_step) in [0, 1)
+    truncates every step to position 0, so every row is the embedding of 0."""
+    emb = bitflip.sinusoidal_table(100, time_input="int64")
+    assert emb.shape == (100, 32)
+    assert np.all(emb[:, :16] == 1.0) and np.all(emb[:, 16:] == 0.0)
+    assert np.array_equal(emb[0], bitflip.sinusoidal_table(100)[0])
+    with pytest.raises(ValueError):
+        bitflip.sinusoidal_table(100, time_input="double")
+
+
 def test_rsqrt_canon_is_accurate():
     for v in (1e-3, 0.0173, 0.5, 1.0, 3.7, 250.0, 1e6):
         r = ref_cpu.rsqrt_canon(v)

@@ -65,6 +65,23 @@ def test_sampler_trajectory_bit_exact(setup):
     assert np.array_equal(traj[0], x0) and np.array_equal(traj[-1], xf)
 
 
+def test_sampler_int64_time_input_bit_exact(setup):
+    """The other reading of the reference's time input (Input dtype int64, mnist_diffusion.py:197: every step embeds
+    position 0): same kernels, a different host-side embedding table; bit-exact against the oracle fed that table, and
+    different from the float reading."""
+    bitflip, model, ref = setup
+    rs = np.random.RandomState(16)
+    T, B, H, W = 100, 2, 28, 28
+    x0 = rs.randint(2, size=(B, H, W)).astype(np.uint8)
+    u = rs.rand(T, B, H, W).astype(np.float32)
+    model_i = bitflip.BitflipModel(model.weights, device=0, time_step=T, time_input="int64")
+    got = bitflip.diffusion_backward(x0[..., None], model_i, T, uniforms=u, return_trajectory=False).cpu().numpy()[..., 0]
+    xf, _ = ref.sample(x0, bitflip.sinusoidal_table(T, time_input="int64"), u, trajectory=True)
+    assert np.array_equal(got, xf)
+    other = bitflip.diffusion_backward(x0[..., None], model, T, uniforms=u, return_trajectory=False).cpu().numpy()[..., 0]
+    assert not np.array_equal(got, other)
+
+
 def test_sampler_philox_uniforms_do_not_depend_on_sharding_or_chunking(setup):
     bitflip, model, _ = setup
     rs = np.random.RandomState(7)

@@ -258,7 +258,7 @@ def _philox_normals_cpu(seed, lattice, elems, t):
     out = np.empty(((elems + 3) // 4) * 4, np.float64)
     for q in range((elems + 3) // 4):
         r = ref_cpu.philox4x32([q, lattice & 0xFFFFFFFF, lattice >> 32, t], [seed & 0xFFFFFFFF, seed >> 32])
-        u = ((r >> 8).astype(np.float64) + 0.5) * 2.0 ** -24
+        u = ((r >> 9).astype(np.float64) + 0.5) * 2.0 ** -23
         m0, m1 = np.sqrt(-2 * np.log(u[0])), np.sqrt(-2 * np.log(u[2]))
         out[4 * q:4 * q + 4] = [m0 * np.cos(2 * np.pi * u[1]), m0 * np.sin(2 * np.pi * u[1]),
                                 m1 * np.cos(2 * np.pi * u[3]), m1 * np.sin(2 * np.pi * u[3])]

@@ -1,0 +1,13 @@
+#!/bin/bash
+set -o pipefail
+mkdir -p gpurun_out/r2
+timeout -k 10 300 python -u -m pytest tests/test_gpu_spectral.py -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/r2/spectral.log 2>&1; rc=$?
+tail -3 gpurun_out/r2/spectral.log; [ $rc -eq 0 ] || { tail -40 gpurun_out/r2/spectral.log; exit 1; }
+for v in 0 1 2 3 4; do
+  IDM_FFT32=$v timeout -k 10 120 python -u tools/bench_elementwise.py > gpurun_out/r2/elem_$v.json 2> gpurun_out/r2/elem_$v.err || { tail -5 gpurun_out/r2/elem_$v.err; exit 1; }
+  python - $v <<'PY'
+import json, sys
+d = json.load(open(f"gpurun_out/r2/elem_{sys.argv[1]}.json"))
+print("fft variant", sys.argv[1], d["kernels"]["irfft2_sign (spectrum in, int8 out)"])
+PY
+done

@@ -19,6 +19,9 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // (v_exp_f32, v_rcp_f32: quarter rate) goes through the packed float32 ALU.
 DEVI f32x4 silu4(f32x4 z)
 {
+#ifdef IDM_EXP_NOSILU   // timing experiment (wrong results): what the activation costs
+    return z;
+#endif
     const f32x2 nl = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.0f, 1.0f};
     f32x2 z0 = {z[0], z[1]}, z1 = {z[2], z[3]};
     f32x2 t0 = z0 * nl, t1 = z1 * nl;
@@ -292,8 +295,24 @@ struct ConvStage {
                 for (int m = 0; m < MS; ++m)
 #pragma unroll
                     for (int n = 0; n < N; ++n)
+#ifdef IDM_EXP_NOMFMA   // timing experiment (wrong results): everything but the MFMAs (operands are still fetched)
+                    {
+                        const bf16x8 ta = wreg[st % WR][ky][m], tb = fr[st & 1][n + ky];
+                        asm volatile("" ::"v"(ta), "v"(tb));
+                    }
+#elif defined(IDM_EXP_MFMA16)   // timing experiment (wrong results): the same operands and FLOPs issued as two 16x16x32 MFMAs
+                    {
+                        f32x4 lo = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
+                        f32x4 hi = {acc[m][n][4], acc[m][n][5], acc[m][n][6], acc[m][n][7]};
+                        lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[st % WR][ky][m], fr[st & 1][n + ky], lo, 0, 0, 0);
+                        hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[st & 1][n + ky], wreg[st % WR][ky][m], hi, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { acc[m][n][r] = lo[r]; acc[m][n][4 + r] = hi[r]; acc[m][n][8 + r] = lo[r] * 0.5f; acc[m][n][12 + r] = hi[r] * 0.5f; }
+                    }
+#else
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[st % WR][ky][m], fr[st & 1][n + ky],
                                                                             acc[m][n], 0, 0, 0);
+#endif
         });
 #pragma unroll
         for (int m = 0; m < MS; ++m)

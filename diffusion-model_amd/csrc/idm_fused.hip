@@ -423,6 +423,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
         }
         float zq[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (EPI2 == E2_HEAD) {
+#ifndef IDM_EXP_NOPHILOX   // timing experiment (wrong results): what the in-kernel noise draw costs
             if (a.do_update && a.add_noise && !a.noise) {
                 const Quad q = quad_of(cur);
                 if (q.act) {
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
                     normal4(((uint64_t)k1 << 32) | k0, a.ph.first_global_index + b, (uint32_t)((q.off - lat) >> 2), a.ph.t, zq);
                 }
             }
+#endif
         }
         TL(3);
 
@@ -600,6 +602,8 @@ constexpr KindInfo kKinds[5] = {
     {M1_UPCAT, 128, 64, 64, 64, E2_STORE, IDM_M3_WAVES == 8 ? 3 : 5, IDM_M3_WAVES == 8 ? 5 : 10, IDM_M3_WAVES},     // FK_M3: [up(conv5), skip2] -> conv6 -> conv7 (whole 16x16 map)
 #if IDM_B_WAVES == 8
     {M1_UPCAT, 64, 32, 32, 32, E2_HEAD, 3, 5, 8},     // FK_B : [up(conv7), skip1] -> conv8 -> conv9 -> head -> update (16-row bands)
+#elif IDM_B_WAVES == 2
+    {M1_UPCAT, 64, 32, 32, 32, E2_HEAD, 6, 12, 2},    // FK_B with two wavefronts (four rows each) and 8-row bands
 #else
     {M1_UPCAT, 64, 32, 32, 32, E2_HEAD, 3, 6, 4},     // FK_B with four wavefronts and 8-row bands
 #endif

@@ -1,6 +1,6 @@
 mkdir -p gpurun_out
 for lib in diffusion-model_amd/isingdiff/libisingdiff.so diffusion-model_amd/isingdiff/abl/lib_*.so diffusion-model_amd/isingdiff/libisingdiff.so; do
-  ISINGDIFF_LIB=$PWD/$lib timeout -k 10 200 python -u bench.py --batch 4096 --T 50 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bv.json 2> gpurun_out/bv.err || { tail -5 gpurun_out/bv.err; exit 1; }
+  ISINGDIFF_LIB=$PWD/$lib timeout -k 10 200 python -u bench.py --batch ${BV_BATCH:-8192} --T 50 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bv.json 2> gpurun_out/bv.err || { tail -5 gpurun_out/bv.err; exit 1; }
   python - "$lib" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/bv.json"))

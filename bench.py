@@ -84,6 +84,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel event timing")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT", help="library tuning switch (idm_set_option), e.g. strip_below_rows=0")
+    ap.add_argument("--fp32-lattices", type=int, default=2048,
+                    help="lattices of the float32 (bit-exact parity mode) companion measurement, N=1 only; 0 skips it")
+    ap.add_argument("--dump-spins", default="", metavar="PREFIX",
+                    help="write the last step's spins of each rank to PREFIX.rank<r>.npy (rehearsal / tests)")
     args = ap.parse_args()
 
     if os.environ.get("ISINGDIFF_BENCH_TRACE"):      # debugging aid: dump every thread's stack after N seconds and exit
@@ -126,9 +130,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    last = {}
+
     def one_step(i):
         res = sample(model, B, L, T=T, betas=betas, seed=42 + i, first_global_index=first, chunk=args.chunk)
         obs = allreduce_observables(res.observables)
+        last["spins"] = res.spins
         return obs
 
     for i in range(args.warmup):
@@ -149,6 +156,22 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    if args.dump_spins:
+        np.save(f"{args.dump_spins}.rank{rank}.npy", last["spins"].cpu().numpy())
+    fp32 = None
+    if rank == 0 and world == 1 and args.precision == "bf16" and args.fp32_lattices > 0:
+        # companion record: the float32 parity mode (canonical-order kernels, bit-exact against the CPU oracle) on the
+        # same lattice size and schedule, outside the timed region of the headline number
+        nb = args.fp32_lattices
+        sample(model, min(nb, 256), L, T=min(T, 20), betas=betas[:min(T, 20)], seed=1, precision="fp32")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sample(model, nb, L, T=T, betas=betas, seed=7, precision="fp32")
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t1
+        fp32 = {"value": nb / d1, "unit": "lattices/s", "lattices": nb, "dtype": "fp32", "seconds": d1,
+                "whole_job_mfma_frac": nb / d1 * FLOP_PER_SITE_FORWARD * L * L * T / (PEAK_FP32_TFLOPS * 1e12),
+                "note": "v_mfma_f32_32x32x2_f32 kernels in canonical summation order (parity mode), one kernel per layer"}
     if rank == 0:
         total = world * B * args.steps
         value = total / dt
@@ -189,6 +212,7 @@ def main():
             "whole_job_mfma_frac": value * flop_per_sample / (world * peak * 1e12),
             "roofline": roof,
             "kernels": kernels,
+            "fp32_companion": fp32,
             "observables": {"mean_E_per_site": obs.mean_energy_per_site() if obs is not None else None,
                             "lattices_in_histogram": int(obs.moments[0]) if obs is not None else 0},
         }

@@ -170,12 +170,14 @@ struct Plan {
     int sR[SK_COUNT], sWS[SK_COUNT];   // band rows / strip columns of the strip kernels
 };
 
+struct StepConst { float c1, c2, sd; };   // x <- ((c1*x) + (c2*score)) + (sd*z)
+
 // Everything the last fused kernel needs to apply the reverse-diffusion update in place.
 struct StepCtx {
     bool do_update = false;
     float *x = nullptr;
     const float *noise = nullptr;
-    float beta = 0.0f;
+    StepConst k = {1.0f, 0.0f, 0.0f};
     bool add_noise = false;
     PhiloxArgs ph = {0, 0, 0};
 };
@@ -308,14 +310,32 @@ int ensure_ws(idm_model *m, size_t bytes)
     return IDM_OK;
 }
 
-// c1 = 1 + 0.5*beta and sd = sqrt(beta), each operation rounded to float32 on the host.
-void step_constants(float beta, float *c1, float *sd)
+// Constants of the reverse step x <- ((c1*x) + (c2*score)) + (sd*z), each operation rounded to float32 on the host
+// (volatile keeps the compiler from contracting or widening them).
+//   IDM_UPDATE_SCORE (b_diffusion_model_unet_2d_ising.py:96): c1 = 1 + 0.5*beta, c2 = beta
+//   IDM_UPDATE_DDPM  (:95): c1 = 1/sqrt(1 - beta), c2 = -(c1 * (beta / sqrt(1 - alpha_cumprod)))
+StepConst step_constants(int rule, float beta, float alpha_cumprod)
 {
-    volatile float half_beta = 0.5f * beta;
-    volatile float one_plus = 1.0f + half_beta;
+    StepConst k;
     volatile float root = sqrtf(beta);
-    *c1 = one_plus;
-    *sd = root;
+    k.sd = root;
+    if (rule == IDM_UPDATE_DDPM) {
+        volatile float om = 1.0f - beta;
+        volatile float rs = sqrtf(om);
+        volatile float a = 1.0f / rs;
+        volatile float oma = 1.0f - alpha_cumprod;
+        volatile float d = sqrtf(oma);
+        volatile float e = beta / d;
+        volatile float ae = a * e;
+        k.c1 = a;
+        k.c2 = -ae;
+    } else {
+        volatile float half_beta = 0.5f * beta;
+        volatile float one_plus = 1.0f + half_beta;
+        k.c1 = one_plus;
+        k.c2 = beta;
+    }
+    return k;
 }
 
 int prof_class(idm_model *m, const char *name)
@@ -394,8 +414,8 @@ int forward_fused(idm_model *m, const Plan &p, const float *x, const float *tadd
         if (head) {
             a.w_head = m->w_head; a.b_head = m->bias[10]; a.score_out = score;
             a.do_update = ctx.do_update ? 1 : 0;
-            a.x = ctx.x; a.noise = ctx.noise; a.add_noise = ctx.add_noise ? 1 : 0; a.ph = ctx.ph; a.beta = ctx.beta;
-            step_constants(ctx.beta, &a.c1, &a.sd);
+            a.x = ctx.x; a.noise = ctx.noise; a.add_noise = ctx.add_noise ? 1 : 0; a.ph = ctx.ph;
+            a.c1 = ctx.k.c1; a.beta = ctx.k.c2; a.sd = ctx.k.sd;
         }
         strip_lds_bytes(sk, a.R, a.WS, &a.lds_in_bytes, &a.lds_stage_bytes, &a.lds_const_bytes);
         hipError_t e = hipSuccess;
@@ -468,8 +488,7 @@ int forward_fused(idm_model *m, const Plan &p, const float *x, const float *tadd
         a.score_out = score;
         a.do_update = ctx.do_update ? 1 : 0;
         a.x = ctx.x; a.noise = ctx.noise; a.add_noise = ctx.add_noise ? 1 : 0; a.ph = ctx.ph;
-        a.beta = ctx.beta;
-        step_constants(ctx.beta, &a.c1, &a.sd);
+        a.c1 = ctx.k.c1; a.beta = ctx.k.c2; a.sd = ctx.k.sd;
         rc = run(FK_B, "fused_B(conv8,9,head,step)", a, Hp, Wp, 2.0 * 9 * (3 * F * F + F * F) * n1 + 2.0 * F * n1,
                  n2 * 2 * F * 2 + n1 * F * 2 + (double)Bc * p.H * p.W * 8);
         if (rc != IDM_OK) return rc;
@@ -790,9 +809,20 @@ int idm_sample(idm_model *m, const idm_sample_cfg *cfg, float *x_dev, const floa
     if (!x_dev) return fail(IDM_ERR_INVALID, "x_dev is null");
     if (cfg->T <= 0 || !cfg->betas_host) return fail(IDM_ERR_INVALID, "T and betas_host are required");
     if (cfg->chunk < 0) return fail(IDM_ERR_INVALID, "negative chunk");
+    if (cfg->update_rule != IDM_UPDATE_SCORE && cfg->update_rule != IDM_UPDATE_DDPM) return fail(IDM_ERR_INVALID, "unknown update_rule");
     HIPCHK(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     const int T = cfg->T;
+    std::vector<float> acp;   // alpha_cumprod[t] for the DDPM rule (:170-173)
+    if (cfg->update_rule == IDM_UPDATE_DDPM) {
+        acp.resize(T);
+        double prod = 1.0;
+        for (int t = 0; t < T; ++t) {
+            prod *= 1.0 - (double)cfg->betas_host[t];
+            acp[t] = cfg->alpha_cumprod_host ? cfg->alpha_cumprod_host[t] : (float)prod;
+            if (!(acp[t] < 1.0f) || !(cfg->betas_host[t] < 1.0f)) return fail(IDM_ERR_INVALID, "the DDPM rule needs beta_t < 1 and alpha_cumprod[t] < 1");
+        }
+    }
     rc = idm_time_table(m, T, nullptr);
     if (rc != IDM_OK) return rc;
     const Plan p = make_plan(m, H, W, cfg->precision);
@@ -819,10 +849,11 @@ int idm_sample(idm_model *m, const idm_sample_cfg *cfg, float *x_dev, const floa
         for (int t = T - 1; t >= 0; --t) {
             float *score = scores_dev ? scores_dev + (size_t)t * total + b0 * elems : score_ws;
             ph.t = t;
+            const StepConst kt = step_constants(cfg->update_rule, cfg->betas_host[t], acp.empty() ? 0.0f : acp[t]);
             const float *z = noise_dev ? noise_dev + (size_t)t * total + b0 * elems : nullptr;
             if (p.fused) {
                 StepCtx ctx;
-                ctx.do_update = true; ctx.x = x; ctx.noise = z; ctx.beta = cfg->betas_host[t];
+                ctx.do_update = true; ctx.x = x; ctx.noise = z; ctx.k = kt;
                 ctx.add_noise = cfg->add_noise != 0; ctx.ph = ph;
                 rc = forward_fused(m, p, x, m->ttable + (size_t)t * nf, scores_dev ? score : nullptr, bc, ctx, nullptr, 0, s);
                 if (rc != IDM_OK) return rc;
@@ -830,7 +861,7 @@ int idm_sample(idm_model *m, const idm_sample_cfg *cfg, float *x_dev, const floa
                 rc = forward_chunk(m, p, x, m->ttable + (size_t)t * nf, score, bc, cfg->precision, nullptr, 0, s);
                 if (rc != IDM_OK) return rc;
                 timed(m, "update", 0.0, (double)bc * elems * (z ? 16 : 12), s, [&] {
-                    launch_update(x, score, z, cfg->betas_host[t], bc, (int64_t)elems, cfg->add_noise != 0, ph, s);
+                    launch_update(x, score, z, kt.c1, kt.c2, kt.sd, bc, (int64_t)elems, cfg->add_noise != 0, ph, s);
                 });
             }
             if (traj_dev)
@@ -847,7 +878,8 @@ int idm_update(int device, float *x_dev, const float *score_dev, const float *z_
     if (!x_dev || !score_dev || n <= 0) return fail(IDM_ERR_INVALID, "bad argument");
     HIPCHK(hipSetDevice(device));
     PhiloxArgs ph = {0, 0, 0};
-    launch_update(x_dev, score_dev, z_dev, beta, 1, n, z_dev != nullptr, ph, (hipStream_t)stream);
+    const StepConst k = step_constants(IDM_UPDATE_SCORE, beta, 0.0f);
+    launch_update(x_dev, score_dev, z_dev, k.c1, k.c2, k.sd, 1, n, z_dev != nullptr, ph, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return IDM_OK;
 }

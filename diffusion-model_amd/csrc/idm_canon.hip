@@ -292,16 +292,13 @@ __global__ __launch_bounds__(256) void update4_kernel(float *__restrict__ x, con
     ((f32x4 *)x)[i] = xv;
 }
 
-void launch_update(float *x, const float *score, const float *z, float beta, int64_t n_lattices, int64_t elems,
+void launch_update(float *x, const float *score, const float *z, float c1, float beta, float sd, int64_t n_lattices, int64_t elems,
                    bool add_noise, const PhiloxArgs &ph, hipStream_t s)
 {
     const int64_t nq = (elems + 3) >> 2;
     const unsigned grid = (unsigned)((n_lattices * nq + 255) / 256);
-    // The three step constants are rounded on the host (IEEE single, one operation each) so that
-    // they do not depend on the device's square-root implementation.
-    volatile float half_beta = 0.5f * beta;
-    volatile float c1 = 1.0f + half_beta;
-    volatile float sd = sqrtf(beta);
+    // (c1, beta = the score coefficient, sd: rounded on the host, so that they do not depend on the device's
+    // square-root implementation)
     const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(score) | reinterpret_cast<uintptr_t>(z);
     if ((elems & 3) == 0 && (al & 15) == 0) {
         hipLaunchKernelGGL(update4_kernel, dim3(grid), dim3(256), 0, s, x, score, z, (float)c1, beta, (float)sd, n_lattices, nq,

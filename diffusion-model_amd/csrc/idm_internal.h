@@ -65,7 +65,8 @@ void launch_head(const float *a9, int64_t B, int H, int W, int Hp, int Wp, int F
                  const float *bias, float *score, hipStream_t s);
 void launch_head_bf16(const void *a9, int64_t B, int H, int W, int Hp, int Wp, int F, int C, const float *w,
                       const float *bias, float *score, hipStream_t s);
-void launch_update(float *x, const float *score, const float *z, float beta, int64_t n_lattices,
+// x <- ((c1*x) + (c2*score)) + (z*sd)
+void launch_update(float *x, const float *score, const float *z, float c1, float c2, float sd, int64_t n_lattices,
                    int64_t elems, bool add_noise, const PhiloxArgs &ph, hipStream_t s);
 void launch_philox_normal(float *out, int64_t n_lattices, int64_t elems, const PhiloxArgs &ph, hipStream_t s);
 void launch_time_table(int T, int n, const float *w0, const float *b0, const float *w1, const float *b1,

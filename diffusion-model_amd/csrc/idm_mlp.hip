@@ -459,6 +459,7 @@ int idm_mlp_sample(idm_mlp *m, const idm_sample_cfg *cfg, float *x_dev, const fl
 {
     if (!m || !cfg || !x_dev || B <= 0 || cfg->T <= 0 || !cfg->betas_host) return idm_set_error(IDM_ERR_INVALID, "bad argument");
     if (cfg->precision != IDM_FP32 && cfg->precision != IDM_BF16) return idm_set_error(IDM_ERR_INVALID, "unknown precision");
+    if (cfg->update_rule != IDM_UPDATE_SCORE) return idm_set_error(IDM_ERR_UNSUPPORTED, "the dense model's sampler has one update rule");
     const bool fast = cfg->precision == IDM_BF16;
     if (fast && !fast_ok(m)) return idm_set_error(IDM_ERR_UNSUPPORTED, "the bf16 dense path needs layer widths that are multiples of 4");
     MLPCHK(hipSetDevice(m->device));

@@ -13,9 +13,11 @@ LIB_PATH = os.environ.get("ISINGDIFF_LIB") or os.path.join(_HERE, "libisingdiff.
 
 IDM_FP32 = 0
 IDM_BF16 = 1
+IDM_UPDATE_SCORE = 0
+IDM_UPDATE_DDPM = 1
 NCONV = 11
 NDENSE = 3
-ABI_VERSION = 1
+ABI_VERSION = 2
 NOALLOC_SCRATCH_BYTES = 64 << 20
 
 
@@ -36,7 +38,7 @@ class SampleCfg(C.Structure):
     _fields_ = [
         ("T", C.c_int32), ("precision", C.c_int32), ("betas_host", C.c_void_p), ("seed", C.c_uint64),
         ("first_global_index", C.c_int64), ("init_state", C.c_int32), ("add_noise", C.c_int32),
-        ("chunk", C.c_int64),
+        ("chunk", C.c_int64), ("update_rule", C.c_int32), ("reserved", C.c_int32), ("alpha_cumprod_host", C.c_void_p),
     ]
 
 
@@ -87,6 +89,9 @@ SIGNATURES = {
     "idm_irfft2_sign": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "idm_metropolis": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_int,
                                  C.c_void_p]),
+    "idm_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]),
+    "idm_allreduce_i64": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p)]),
+    "idm_comm_destroy": (C.c_int, [C.c_void_p]),
     "idm_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "idm_profile_begin": (C.c_int, [C.c_void_p]),
     "idm_profile_end": (C.c_int, [C.c_void_p, C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),

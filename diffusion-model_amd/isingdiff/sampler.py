@@ -22,9 +22,22 @@ def beta_schedule(T: int = 1000) -> np.ndarray:
     return np.linspace(1e-4, 0.02, T).astype(np.float32)
 
 
+UPDATE_RULES = {"score": _lib.IDM_UPDATE_SCORE, "ddpm": _lib.IDM_UPDATE_DDPM}
+
+
+def alpha_cumprod(beta_lst) -> np.ndarray:
+    """``float32(np.cumprod(1 - noise_beta))`` (:169-173), in the precision ``beta_lst`` comes in (the reference's
+    ``noise_beta`` is float64)."""
+    return np.cumprod(1.0 - np.asarray(beta_lst)).astype(np.float32)
+
+
 def _run(model: ScoreModel, x: torch.Tensor, betas: np.ndarray, T: int, *, noise: Optional[torch.Tensor],
          traj: Optional[torch.Tensor], scores: Optional[torch.Tensor], spins: Optional[torch.Tensor],
-         precision: int, seed: int, first_global_index: int, init_state: bool, add_noise: bool, chunk: int):
+         precision: int, seed: int, first_global_index: int, init_state: bool, add_noise: bool, chunk: int,
+         update_rule: str = "score"):
+    if update_rule not in UPDATE_RULES:
+        raise ValueError(f"update_rule must be one of {sorted(UPDATE_RULES)}")
+    acp = alpha_cumprod(betas) if update_rule == "ddpm" else None
     betas = np.ascontiguousarray(betas, np.float32)
     if betas.shape != (T,):
         raise ValueError(f"beta_lst must have T={T} entries")
@@ -38,6 +51,8 @@ def _run(model: ScoreModel, x: torch.Tensor, betas: np.ndarray, T: int, *, noise
     cfg.init_state = int(init_state)
     cfg.add_noise = int(add_noise)
     cfg.chunk = chunk
+    cfg.update_rule = UPDATE_RULES[update_rule]
+    cfg.alpha_cumprod_host = None if acp is None else acp.ctypes.data
     p = lambda t: None if t is None else t.data_ptr()
     with torch.cuda.device(model.device):
         _lib.check(_lib.load().idm_sample(model.handle, C.byref(cfg), x.data_ptr(), p(noise), p(traj), p(scores),
@@ -45,7 +60,8 @@ def _run(model: ScoreModel, x: torch.Tensor, betas: np.ndarray, T: int, *, noise
 
 
 def diffusion_backward(x_asym, beta_lst, score_model: ScoreModel, T: int, *, noise=None, return_trajectory=True,
-                       precision=None, seed: int = 42, first_global_index: int = 0, return_scores=False):
+                       precision=None, seed: int = 42, first_global_index: int = 0, return_scores=False,
+                       update_rule: str = "score"):
     """``diffusion_backward(x_asym, beta_lst, score_model, T)`` of the reference (:81-98).
 
     Returns ``(T+1, B, H, W, C)`` with index 0 the final state, like the reference
@@ -54,6 +70,8 @@ def diffusion_backward(x_asym, beta_lst, score_model: ScoreModel, T: int, *, noi
     noise: ``None`` draws each step's standard normals in-kernel from Philox(seed); an array
     ``(T, B,H,W,C)`` indexed by t injects them (deterministic mode: step t adds
     ``noise[t] * sqrt(beta_t)``); ``False`` disables the noise term.
+    update_rule: ``"score"`` is the update the reference runs (:96); ``"ddpm"`` the commented-out alternative (:95),
+    ``x = (x - beta_t / sqrt(1 - alpha_cumprod[t]) * score) / sqrt(1 - beta_t) + noise``.
     Output type follows ``x_asym`` (numpy or torch).
     """
     prec = score_model.precision if precision is None else _precision_code(precision)
@@ -75,7 +93,8 @@ def diffusion_backward(x_asym, beta_lst, score_model: ScoreModel, T: int, *, noi
     scores = torch.empty((T,) + tuple(x.shape), dtype=torch.float32, device=x.device) if return_scores else None
     if x.shape[0] > 0:
         _run(score_model, x, np.asarray(beta_lst), T, noise=z, traj=traj, scores=scores, spins=None, precision=prec,
-             seed=seed, first_global_index=first_global_index, init_state=False, add_noise=add_noise, chunk=0)
+             seed=seed, first_global_index=first_global_index, init_state=False, add_noise=add_noise, chunk=0,
+             update_rule=update_rule)
     out = traj if return_trajectory else x
     conv = (lambda t: t) if is_torch else (lambda t: t.cpu().numpy())
     return (conv(out), conv(scores)) if return_scores else conv(out)
@@ -90,7 +109,7 @@ class SampleResult:
 
 def sample(model: ScoreModel, n: int, L: int, *, T: int = 1000, betas=None, seed: int = 42, precision=None,
            first_global_index: int = 0, chunk: int = 0, keep_state: bool = False, observables: bool = True,
-           x_T=None, noise=None, width: Optional[int] = None) -> SampleResult:
+           x_T=None, noise=None, width: Optional[int] = None, update_rule: str = "score") -> SampleResult:
     """Draw ``n`` L×L lattices: x_T ~ N(0,1) (Philox, keyed by the global lattice index), the full
     reverse schedule, sign projection (:203-213) and — for single-channel models — the Ising
     observables.  Everything stays on the GPU."""
@@ -114,7 +133,7 @@ def sample(model: ScoreModel, n: int, L: int, *, T: int = 1000, betas=None, seed
     spins = torch.empty(shape, dtype=torch.int8, device=model.device)
     if n > 0:
         _run(model, x, betas, T, noise=z, traj=None, scores=None, spins=spins, precision=prec, seed=seed,
-             first_global_index=first_global_index, init_state=init, add_noise=True, chunk=chunk)
+             first_global_index=first_global_index, init_state=init, add_noise=True, chunk=chunk, update_rule=update_rule)
     obs = None
     if model.channels == 2 and width == L // 2 + 1 and n > 0:
         from .spectral import irfft2_sign

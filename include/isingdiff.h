@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define IDM_ABI_VERSION 1
+#define IDM_ABI_VERSION 2
 
 typedef enum {
     IDM_OK = 0,
@@ -47,6 +47,14 @@ typedef enum {
     IDM_FP32 = 0,  /* float32 activations, float32 MFMA; canonical summation order (deterministic parity mode) */
     IDM_BF16 = 1   /* bfloat16 activations and weights on bf16 MFMA, float32 accumulate / state */
 } idm_precision;
+
+/* The reverse step x <- c1*x + c2*score + sqrt(beta_t)*z of b_diffusion_model_unet_2d_ising.py:
+ *   IDM_UPDATE_SCORE  c1 = 1 + beta_t/2,        c2 = beta_t                                         (:96, what the script runs)
+ *   IDM_UPDATE_DDPM   c1 = 1/sqrt(1 - beta_t),  c2 = -c1 * beta_t / sqrt(1 - alpha_cumprod[t])      (:95, commented out there:
+ *                     the ancestral DDPM step for a model that predicts the noise, which is what the saved weights do)
+ * The three constants are rounded to float32 on the host, one IEEE operation at a time; the device evaluates
+ * ((c1*x) + (c2*score)) + (sd*z) with every product and sum rounded separately. */
+typedef enum { IDM_UPDATE_SCORE = 0, IDM_UPDATE_DDPM = 1 } idm_update_rule;
 
 #define IDM_NCONV 11
 #define IDM_NDENSE 3
@@ -81,6 +89,10 @@ typedef struct {
     int32_t init_state;           /* 1: draw x_T ~ N(0,1) from Philox into x_dev first; 0: x_dev holds x_T */
     int32_t add_noise;            /* 1: add noise every step (reference behaviour); 0: deterministic drift only */
     int64_t chunk;                /* lattices processed together (bounds the workspace); 0 = automatic */
+    int32_t update_rule;          /* idm_update_rule; 0 = the rule the reference runs (:96) */
+    int32_t reserved;
+    const float *alpha_cumprod_host; /* IDM_UPDATE_DDPM: T float32 values alpha_cumprod[t] (:170-173), or NULL to have
+                                        them computed as float32(cumprod(1 - betas)) in double precision */
 } idm_sample_cfg;
 
 int idm_abi_version(void);
@@ -169,6 +181,18 @@ int idm_irfft2_sign(int device, const float *spec_dev, int64_t B, int L, int8_t 
  * sweep0: index of the first sweep (continue a chain with sweep0 += n_sweeps). */
 int idm_metropolis(int device, int8_t *spins_dev, int64_t B, int L, const float *accept_host, int n_sweeps,
                    uint64_t seed, int64_t first_global_index, int sweep0, void *stream);
+
+/* Histogram exchange for a C caller that drives several GPUs from one process (no counterpart in the reference,
+ * which is single-device; the sharded sampler needs exactly one exchange: the sum of the observable histograms
+ * and moments).  idm_comm_create builds an RCCL communicator over `devices` (ncclCommInitAll; librccl is bound at
+ * run time and only needed for n > 1); idm_allreduce_i64 sums `count` int64 values element-wise over the n device
+ * buffers, in place (per_device_bufs[i] lives on devices[i]; streams[i] or NULL = default stream; enqueues and
+ * returns).  With n = 1 it is the identity.  The Python host path uses torch.distributed (backend "nccl", which
+ * is RCCL) for the same exchange, one process per GPU. */
+typedef struct idm_comm idm_comm;
+int idm_comm_create(idm_comm **out, const int *devices, int n);
+int idm_allreduce_i64(idm_comm *c, int64_t *const *per_device_bufs, size_t count, void *const *streams);
+int idm_comm_destroy(idm_comm *c);
 
 /* Tuning switches (no counterpart in the reference).  "fused" (default 1): bf16 forward uses
  * the fused two-convolution band kernels when the shape fits; 0 forces one kernel per layer. */
@@ -279,7 +303,7 @@ int idm_mlp_forward(idm_mlp *m, const float *x_dev, float t_norm, float *score_d
 int idm_mlp_forward_precision(idm_mlp *m, const float *x_dev, float t_norm, float *score_dev, int64_t B, int precision,
                               void *stream);
 
-/* diffusion_backward (:19-38): cfg as for idm_sample (chunk unused); both precisions draw the same noise.
+/* diffusion_backward (:19-38): cfg as for idm_sample (chunk unused, update_rule must be IDM_UPDATE_SCORE); both precisions draw the same noise.
  * x_dev (B, n): x_T on entry (or drawn here when cfg->init_state), final state on return;
  * noise_dev NULL or (T, B, n) standard normals indexed by t; traj_dev NULL or (T+1, B, n) with
  * traj[T] = x_T and traj[t] = state after step t (the reference's return layout). */

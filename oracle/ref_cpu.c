@@ -325,8 +325,51 @@ void ref_update(float *x, const float *score, const float *z, float beta, size_t
     }
 }
 
+/* The commented-out alternative update of b_diffusion_model_unet_2d_ising.py:95 (ancestral DDPM step for a noise-predicting
+ * model):  x <- (1/sqrt(1-beta)) * (x - beta/sqrt(1-alpha_cumprod) * score) + noise, restated in the same canonical form as
+ * ref_update: x <- ((c1*x) + (c2*score)) + (z*sd) with c1 = 1/sqrt(1-beta), c2 = -(c1 * (beta / sqrt(1-alpha_cumprod))),
+ * every operation rounded to float32. */
+void ref_update_ddpm(float *x, const float *score, const float *z, float beta, float alpha_cumprod, size_t n)
+{
+    const float om = 1.0f - beta;
+    const float rs = sqrtf(om);
+    const float c1 = 1.0f / rs;
+    const float oma = 1.0f - alpha_cumprod;
+    const float d = sqrtf(oma);
+    const float e = beta / d;
+    const float ae = c1 * e;
+    const float c2 = -ae;
+    const float sd = sqrtf(beta);
+    for (size_t i = 0; i < n; ++i) {
+        float a = c1 * x[i];
+        float b = c2 * score[i];
+        float s = a + b;
+        if (z) { float nz = z[i] * sd; s = s + nz; }
+        x[i] = s;
+    }
+}
+
 /* Full reverse schedule, t = T-1 .. 0.  noise_z: (T, B*H*W*C) standard normals indexed by t,
- * or NULL.  scores_out: optional (T, n) per-step score record indexed by t. */
+ * or NULL.  scores_out: optional (T, n) per-step score record indexed by t.
+ * alpha_cumprod: NULL = the update the reference runs (:96); else T values and the DDPM update (:95). */
+void ref_sample_rule(const ref_model *m, float *x, const float *betas, const float *alpha_cumprod, int T, const float *noise_z,
+                     int B, int H, int W, float *scores_out)
+{
+    const size_t n = (size_t)B * H * W * m->channels;
+    const int nf = 4 * m->filters;
+    float *score = (float *)malloc(n * sizeof(float));
+    float *tadd = (float *)malloc(nf * sizeof(float));
+    for (int t = T - 1; t >= 0; --t) {
+        ref_time_add(m, (float)t / (float)T, tadd);
+        ref_forward(m, x, tadd, score, B, H, W);
+        if (scores_out) memcpy(scores_out + (size_t)t * n, score, n * sizeof(float));
+        const float *z = noise_z ? noise_z + (size_t)t * n : NULL;
+        if (alpha_cumprod) ref_update_ddpm(x, score, z, betas[t], alpha_cumprod[t], n);
+        else ref_update(x, score, z, betas[t], n);
+    }
+    free(score); free(tadd);
+}
+
 void ref_sample(const ref_model *m, float *x, const float *betas, int T, const float *noise_z,
                 int B, int H, int W, float *scores_out)
 {

@@ -195,6 +195,30 @@ def test_sampler_fp32_injected_noise_bit_exact(gpu_real, ref_real):
     assert np.array_equal(obs.M.cpu().numpy(), M) and np.array_equal(obs.S.cpu().numpy(), S)
 
 
+def test_sampler_ddpm_update_rule(gpu_real, ref_real):
+    """The reference's alternative update (b_diffusion_model_unet_2d_ising.py:95, commented out there), selected with
+    update_rule="ddpm": float32 free run bit-exact against the oracle's restatement of that line, and - unlike the
+    update the script runs (:96), which diverges to ~1e24 - it stays bounded, because it is the ancestral DDPM step
+    for the noise-predicting model the saved weights are.  bf16 (fused kernels, Philox noise) gives ordered lattices."""
+    from isingdiff.sampler import alpha_cumprod, beta_schedule, diffusion_backward, sample
+    B, L, T = 2, 20, 1000
+    rs = np.random.RandomState(5)
+    x_T = rs.standard_normal((B, L, L, 1)).astype(np.float32)
+    z = rs.standard_normal((T, B, L, L, 1)).astype(np.float32)
+    betas = beta_schedule(T)
+    want = ref_real.sample(x_T, betas, T, noise_z=z, alpha_cumprod=alpha_cumprod(betas))
+    got = diffusion_backward(x_T, betas, gpu_real, T, noise=z, precision="fp32", return_trajectory=False, update_rule="ddpm")
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.abs(want).max() < 50.0
+    other = diffusion_backward(x_T, betas, gpu_real, T, noise=z, precision="fp32", return_trajectory=False)
+    assert np.abs(other).max() > 1e10
+    res = sample(gpu_real, 512, 32, T=T, seed=3, precision="bf16", update_rule="ddpm", keep_state=True)
+    assert float(res.x_final.abs().max()) < 1e3        # (the other rule reaches 1e24; a few outliers of O(50) at L = 32)
+    assert res.observables.mean_energy_per_site() < -1.0
+    with pytest.raises(ValueError):
+        sample(gpu_real, 4, 20, T=10, update_rule="euler")
+
+
 def test_sampler_matches_golden(gpu_real):
     """Committed fixture (tests/golden/make_golden.py): B=4, L=20, RandomState(0) noise."""
     import os

@@ -96,7 +96,7 @@ def test_c_abi_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from isingdiff import _lib
     assert C.sizeof(_lib.ModelDesc) == 16 + 8 * (4 * 11 + 2 * 3)
-    assert C.sizeof(_lib.SampleCfg) == 48
+    assert C.sizeof(_lib.SampleCfg) == 64
     assert C.sizeof(_lib.ProfileEntry) == 32 + 8 * 4
 
 

@@ -137,3 +137,32 @@ def test_philox_known_answer():
     assert list(ref_cpu.philox4x32([0xffffffff] * 4, [0xffffffff] * 2)) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert list(ref_cpu.philox4x32([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_ddpm_update_rule_is_the_stable_one(ref_real):
+    """The commented-out update of b_diffusion_model_unet_2d_ising.py:95, restated in ref_update_ddpm: against a float64
+    evaluation of the line as written, and as a free run - it is the ancestral DDPM step for a model that predicts the
+    noise (which the saved weights do, see the correlation probes above), so the state stays O(1) and orders, where the
+    update the script runs (:96) diverges."""
+    from oracle import ref_cpu
+    from oracle.ref_cpu import beta_schedule
+    T = 1000
+    noise_beta = np.linspace(1e-4, 0.02, T)
+    acp = np.cumprod(1 - noise_beta).astype(np.float32)
+    betas = beta_schedule(T)
+    rs = np.random.RandomState(5)
+    # one step against the formula of :95 in float64
+    x = rs.standard_normal(64).astype(np.float32); s = rs.standard_normal(64).astype(np.float32)
+    z = rs.standard_normal(64).astype(np.float32)
+    t = 700
+    got = x.copy()
+    ref_cpu.lib().ref_update_ddpm(got.ctypes.data, s.ctypes.data, z.ctypes.data, ref_cpu.C.c_float(betas[t]), ref_cpu.C.c_float(acp[t]), 64)
+    b, a = np.float64(betas[t]), np.float64(acp[t])
+    want = (1 / np.sqrt(1 - b)) * (x.astype(np.float64) - (b / np.sqrt(1 - a)) * s) + z * np.sqrt(b)
+    assert np.abs(got - want).max() < 1e-6
+    # free run
+    x_T = rs.standard_normal((1, 20, 20, 1)).astype(np.float32)
+    zz = rs.standard_normal((T, 1, 20, 20, 1)).astype(np.float32)
+    out = ref_real.sample(x_T, betas, T, noise_z=zz, alpha_cumprod=acp)
+    assert np.abs(out).max() < 10.0
+    assert abs(np.sign(out).mean()) > 0.8

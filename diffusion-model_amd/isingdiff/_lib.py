@@ -89,6 +89,9 @@ SIGNATURES = {
     "idm_irfft2_sign": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "idm_metropolis": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_int,
                                  C.c_void_p]),
+    "idm_xy_metropolis": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64, C.c_int64, C.c_int,
+                                    C.c_void_p]),
+    "idm_xy_observe": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "idm_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]),
     "idm_allreduce_i64": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p)]),
     "idm_comm_destroy": (C.c_int, [C.c_void_p]),

@@ -182,6 +182,19 @@ int idm_irfft2_sign(int device, const float *spec_dev, int64_t B, int L, int8_t 
 int idm_metropolis(int device, int8_t *spins_dev, int64_t B, int L, const float *accept_host, int n_sweeps,
                    uint64_t seed, int64_t first_global_index, int sweep0, void *stream);
 
+/* 2-D XY model (XY_model/xymetoropolis.c, the reference's C program).  theta_dev (B,L,L) float32: angles in turns,
+ * theta / 2 pi in [0, 1), as the reference's field2d holds them (there in double).
+ * idm_xy_metropolis: n_sweeps sweeps of the single-site move of xy_sampling (:169-211: proposal x + (u - 1/2)*delta with
+ *   delta = 0.1 in the reference, wrapped into [0,1); accept when dE <= 0 or exp(-beta*dE) > u'), the two checkerboard
+ *   colours in turn with Philox uniforms instead of one random site per libc rand() draw: same stationary distribution,
+ *   one independent chain per lattice; sweep0 = index of the first sweep (continue a chain with sweep0 += n_sweeps).
+ * idm_xy_observe: per lattice xyenergy (:32-50, energy per site), xymagnetization (:53-69), and the counts of +1 / -1
+ *   plaquette windings of xyvortex (:71-121), evaluated in float64; any output may be NULL. */
+int idm_xy_metropolis(int device, float *theta_dev, int64_t B, int L, float beta, float delta, int n_sweeps, uint64_t seed,
+                      int64_t first_global_index, int sweep0, void *stream);
+int idm_xy_observe(int device, const float *theta_dev, int64_t B, int L, double *energy_dev, double *magnetization_dev,
+                   int32_t *vortex_pos_dev, int32_t *vortex_neg_dev, void *stream);
+
 /* Histogram exchange for a C caller that drives several GPUs from one process (no counterpart in the reference,
  * which is single-device; the sharded sampler needs exactly one exchange: the sum of the observable histograms
  * and moments).  idm_comm_create builds an RCCL communicator over `devices` (ncclCommInitAll; librccl is bound at

@@ -143,6 +143,14 @@ struct ConvStage {
     LaneGeo g;
     int h, r0, nrows, Rh, f, f1, up_rb;
     bf16x8 wreg[WR][3][MS];
+    // A stage whose weights fit the ring as a whole (FULL) and that has a single cout slice needs them fetched only
+    // once per kernel: they stay in registers from band to band (IDM_STATIONARY_WEIGHTS, on by default).
+    static constexpr bool STATIONARY = FULL && NSL == 1
+#ifdef IDM_NO_STATIONARY_WEIGHTS
+                                       && false
+#endif
+        ;
+    bool loaded = false;
 
     DEVI void set_slice(int sl)
     {
@@ -189,7 +197,13 @@ struct ConvStage {
         const int tot = NSL * g.ncb * Rh;
         f = (wave * tot) / nwaves;
         f1 = ((wave + 1) * tot) / nwaves;
-        if (f < f1) {
+        if constexpr (STATIONARY) {
+            if (!loaded) {   // every wavefront, whether or not it has work in this band
+                set_slice(0);
+                prologue();
+                loaded = true;
+            }
+        } else if (f < f1) {
             set_slice(unit_of(f) % NSL);
             prologue();
         }
@@ -335,7 +349,7 @@ struct ConvStage {
 #pragma unroll
             for (int k = 1; k < NT; ++k) cnt += k * np < len;
             const int sl = u % NSL, cb = u / NSL;
-            if (!fetched) {
+            if (!fetched && !STATIONARY) {
                 set_slice(sl);
                 prologue();
             }

@@ -10,6 +10,10 @@ namespace {
 
 constexpr int WG = 256;
 
+#ifndef IDM_FRAG_DEPTH
+#define IDM_FRAG_DEPTH 1
+#endif
+
 enum { M1_PLAIN = 0, M1_UPCAT = 1, M1_FIRST = 2 };
 enum { E2_STORE = 0, E2_STORE_POOL = 1, E2_HEAD = 2 };
 
@@ -21,6 +25,15 @@ DEVI f32x4 silu4(f32x4 z)
 {
 #ifdef IDM_EXP_NOSILU   // timing experiment (wrong results): what the activation costs
     return z;
+#endif
+#ifdef IDM_SILU_SCALAR  // one float at a time (build with -fno-slp-vectorize, or the compiler packs it again)
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float e = __builtin_amdgcn_exp2f(z[i] * -1.4426950408889634f);
+        o[i] = z[i] * __builtin_amdgcn_rcpf(e + 1.0f);
+    }
+    return o;
 #endif
     const f32x2 nl = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.0f, 1.0f};
     f32x2 z0 = {z[0], z[1]}, z1 = {z[2], z[3]};
@@ -175,6 +188,9 @@ struct ConvStage {
                 // the low 12 bits of the constant ride in the instruction's immediate offset, so the
                 // fetches of a stage share a few scalar 4 KB bases instead of one scalar constant each
                 const unsigned k = (((ky * 3 + kx) * NCG + cg) * MTOT + m) * 1024;
+#ifdef IDM_EXP_HALFW   // timing experiment (wrong results): odd supersteps reuse the previous superstep's weight fragments
+                if constexpr (S & 1) { wreg[S % WR][ky][m] = wreg[(S - 1) % WR][ky][m]; continue; }
+#endif
                 wreg[S % WR][ky][m] = buf_load16(wrsrc, woff + (k & 0xFFFu), k & ~0xFFFu);
             }
     }
@@ -262,7 +278,10 @@ struct ConvStage {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
-        bf16x8 fr[2][N + 2];
+        // activation fragments are read FD supersteps ahead of their MFMAs (LDS latency under load exceeds the MFMA time
+        // of a superstep with few tiles)
+        constexpr int FD = IDM_FRAG_DEPTH < NS ? IDM_FRAG_DEPTH : 1, FR = FD + 1;
+        bf16x8 fr[FR][N + 2];
         auto read_f = [&](auto S) {
             constexpr int st = decltype(S)::value;
             constexpr int kx = st / NCG, cg = st % NCG;
@@ -272,9 +291,9 @@ struct ConvStage {
                     int addr;
                     if constexpr (UP) addr = a_up[i] + c_up[kx];
                     else addr = a_pl[i] + kx * SA;
-                    fr[st & 1][i] = *(const bf16x8 *)(lds_a + addr + cg * 32);
+                    fr[st % FR][i] = *(const bf16x8 *)(lds_a + addr + cg * 32);
                 } else {
-                    fr[st & 1][i] = *(const bf16x8 *)(lds_b + a_b[i] + kx * SB + (cg - NCG_A) * 32);
+                    fr[st % FR][i] = *(const bf16x8 *)(lds_b + a_b[i] + kx * SB + (cg - NCG_A) * 32);
                 }
             }
         };
@@ -285,14 +304,20 @@ struct ConvStage {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) k1[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        read_f(std::integral_constant<int, 0>{});
+        static_for<0, FD>([&](auto S) { read_f(S); });
         static_for<0, NS>([&](auto S) {
             constexpr int st = decltype(S)::value;
             // pin the software pipeline: without this the scheduler hoists every load of the
             // unrolled loop to the top and spills
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (st + NPRE < NS) issue_w<st + NPRE>();
-            if constexpr (st + 1 < NS) read_f(std::integral_constant<int, st + 1>{});
+            if constexpr (st + FD < NS) read_f(std::integral_constant<int, st + FD>{});
+#ifdef IDM_PIN_LOADS
+            // ... and keep the scheduler from sinking the fragment reads to just before their first use (it does, to
+            // reuse the registers of the fragments that die during this superstep, which exposes the LDS latency
+            // once per superstep)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             if constexpr (st == NS - 1) {
 #pragma unroll
                 for (int m = 0; m < MS; ++m)
@@ -311,20 +336,20 @@ struct ConvStage {
                     for (int n = 0; n < N; ++n)
 #ifdef IDM_EXP_NOMFMA   // timing experiment (wrong results): everything but the MFMAs (operands are still fetched)
                     {
-                        const bf16x8 ta = wreg[st % WR][ky][m], tb = fr[st & 1][n + ky];
+                        const bf16x8 ta = wreg[st % WR][ky][m], tb = fr[st % FR][n + ky];
                         asm volatile("" ::"v"(ta), "v"(tb));
                     }
 #elif defined(IDM_EXP_MFMA16)   // timing experiment (wrong results): the same operands and FLOPs issued as two 16x16x32 MFMAs
                     {
                         f32x4 lo = {acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]};
                         f32x4 hi = {acc[m][n][4], acc[m][n][5], acc[m][n][6], acc[m][n][7]};
-                        lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[st % WR][ky][m], fr[st & 1][n + ky], lo, 0, 0, 0);
-                        hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[st & 1][n + ky], wreg[st % WR][ky][m], hi, 0, 0, 0);
+                        lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[st % WR][ky][m], fr[st % FR][n + ky], lo, 0, 0, 0);
+                        hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[st % FR][n + ky], wreg[st % WR][ky][m], hi, 0, 0, 0);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { acc[m][n][r] = lo[r]; acc[m][n][4 + r] = hi[r]; acc[m][n][8 + r] = lo[r] * 0.5f; acc[m][n][12 + r] = hi[r] * 0.5f; }
                     }
 #else
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[st % WR][ky][m], fr[st & 1][n + ky],
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[st % WR][ky][m], fr[st % FR][n + ky],
                                                                             acc[m][n], 0, 0, 0);
 #endif
         });

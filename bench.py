@@ -32,9 +32,10 @@ PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA
 PEAK_FP32_TFLOPS = 157.3              # MI355X fp32 MFMA
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per lattice per launch of the dominant kernel at L=32 (x, skip1 and the conv7 map in,
-# x out), from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes kept in profiles/r01/v6_pmc_hbm.txt
+# x out), from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes kept in profiles/r02/pmc_hbm.txt
 # (FETCH_SIZE doubled: gfx950 counts 16-byte-per-lane streaming reads at half their bytes).
-PMC_HBM_BYTES_PER_LATTICE = {"fused_B(conv8,9,head,step)": 106.3 * 1024}
+# Counters cannot be read inside this script; tools/measure_round.sh collects them with the same library.
+PMC_HBM_BYTES_PER_LATTICE = {"fused_B(conv8,9,head,step)": 105.9 * 1024}
 
 
 def cpu_baseline(spec, L, T, betas, budget_s=20.0):
@@ -195,7 +196,7 @@ def main():
                 lat_per_launch = B * args.steps * 1.0 / (dom["launches"] / T)
                 roof = {"bound": "mfma", "kernel": dom["name"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                         "frac": ach / peak, "traffic": per_lat * lat_per_launch if per_lat else None,
-                        "traffic_unit": "HBM bytes per launch (PMC, profiles/r01/v6_pmc_hbm.txt)",
+                        "traffic_unit": "HBM bytes per launch (PMC, profiles/r02/pmc_hbm.txt)",
                         "flop_per_launch": dom["flop"] / dom["launches"], "avg_launch_us": 1e3 * dom["ms"] / dom["launches"],
                         "share_of_gpu_time": dom["ms"] / tot_ms}
             else:

@@ -204,7 +204,8 @@ def main():
                 roof = {"bound": "hbm", "kernel": dom["name"], "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": ach / PEAK_HBM_GBS, "traffic": None}
         out = {
-            "metric": "denoised Ising lattice samples/sec (whole node) at L=32, full schedule",
+            "metric": "denoised Ising lattice samples/sec (whole node) at L=32, full schedule" if (L, T) == (32, 1000)
+            else f"denoised Ising lattice samples/sec (whole node) at L={L}, {T}-step slice",
             "value": value, "unit": "lattices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic (Philox N(0,1) x_T and per-step noise; saved .keras weights)",

@@ -49,6 +49,20 @@ DEVI f32x4 silu4(f32x4 z)
     return f32x4{z0[0], z0[1], z1[0], z1[1]};
 }
 
+// silu of one value on the plain (unpacked) float32 ALU.
+DEVI float silu1(float z)
+{
+#ifdef IDM_EXP_NOSILU
+    return z;
+#endif
+#ifdef IDM_EXP_FOLDSILU   // timing experiment (wrong results): the activation without its input scaling
+    const float e = __builtin_amdgcn_exp2f(z);
+#else
+    const float e = __builtin_amdgcn_exp2f(z * -1.4426950408889634f);
+#endif
+    return z * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
 DEVI bf16x4 pack4(float a, float b, float c, float d)
 {
     bf16x4 o = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
@@ -236,8 +250,12 @@ struct ConvStage {
         return u;
     }
 
-    template <int N, class Epi>
-    DEVI void piece(int j, int sl, int cb, Epi &&epi)
+    struct NoHook { DEVI void operator()(int) const {} };
+
+    // hook(0): operands addressed, before the first fragment read; hook(1): after the last MFMA; hook(2): after the
+    // epilogue; hook(3 + i): after the epilogue of the piece's i-th tile, i < 3 (timing builds; a no-op otherwise).
+    template <int N, class Epi, class Hook>
+    DEVI void piece(int j, int sl, int cb, Epi &&epi, Hook &&hook)
     {
         const int W = g.W, Wp2 = W + 2, Wh2 = (W >> 1) + 2;
         const int cc = cb * 32 + g.col;
@@ -304,6 +322,10 @@ struct ConvStage {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) k1[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        hook(0);
+#ifdef IDM_EXP_PRIO_MFMA   // timing experiment: the MFMA loop at raised issue priority
+        __builtin_amdgcn_s_setprio(IDM_EXP_PRIO_MFMA);
+#endif
         static_for<0, FD>([&](auto S) { read_f(S); });
         static_for<0, NS>([&](auto S) {
             constexpr int st = decltype(S)::value;
@@ -353,15 +375,39 @@ struct ConvStage {
                                                                             acc[m][n], 0, 0, 0);
 #endif
         });
+#ifdef IDM_EXP_PRIO_MFMA
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef IDM_EXP_PRIO_EPI   // timing experiment: the epilogue at raised issue priority
+        __builtin_amdgcn_s_setprio(IDM_EXP_PRIO_EPI);
+#endif
+        hook(1);
+#ifdef IDM_TIMELINE   // what the epilogue's first instructions wait for: the constants' LDS reads, then the last MFMAs
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        hook(6);
+        {
+            float t0 = acc[0][0][0], t1 = acc[0][N - 1][0];
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(t0) : "v"(t1));
+            asm volatile("s_nop 0" ::"v"(t0));
+        }
+        hook(7);
+#endif
 #pragma unroll
         for (int m = 0; m < MS; ++m)
 #pragma unroll
             for (int n = 0; n < N; ++n)
+            {
                 epi(acc[m][n], k0[m], k1[m], sl * MS + m, rbase + n, cc, g.ok && cc < W && j + n + g.slot * Rh < nrows);
+                if (m * N + n < 3) hook(3 + m * N + n);
+            }
+#ifdef IDM_EXP_PRIO_EPI
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        hook(2);
     }
 
-    template <class Epi>
-    DEVI void run(Epi &&epi)
+    template <class Epi, class Hook = NoHook>
+    DEVI void run(Epi &&epi, Hook &&hook = Hook{})
     {
         bool fetched = true;
 #pragma unroll 1
@@ -380,7 +426,7 @@ struct ConvStage {
             }
             fetched = false;
             static_for<1, NT + 1>([&](auto N) {
-                if (cnt == decltype(N)::value) piece<decltype(N)::value>(j, sl, cb, epi);
+                if (cnt == decltype(N)::value) piece<decltype(N)::value>(j, sl, cb, epi, hook);
             });
             f += cnt;
         }

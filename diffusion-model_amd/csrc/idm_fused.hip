@@ -177,19 +177,33 @@ DEVI void clear_halo(char *tile, int W, int nrows, int z0, int z1, int tid)
 }  // namespace
 
 #ifdef IDM_TIMELINE
-// Debug build only: phase timestamps of one workgroup (wavefronts 0 and 3), [kind][wave sel][band][stamp].
-__device__ long long g_tl[5][2][64][10];
+// Debug build only: phase timestamps of one workgroup (wavefronts 0 and 3), [kind][wave sel][band][stamp], and, for
+// fused_B, of wavefront 0 of the first 1024 workgroups during bands 8-23 together with the hardware id of the CU they
+// run on (to line up the workgroups that share a CU).
+__device__ long long g_tl[5][2][64][32];
+__device__ long long g_tl2[1024][16][16];
+__device__ unsigned g_hw[1024][2];
 extern "C" int idm_debug_timeline(long long *host)
 {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl), sizeof(g_tl));
+}
+extern "C" int idm_debug_timeline2(long long *host, unsigned *hw)
+{
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl2), sizeof(g_tl2));
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_hw), sizeof(g_hw));
+    return (int)e;
 }
 #define TL(i)                                                                                          \
     do {                                                                                               \
         if (blockIdx.x == 7 && lane == 0 && (wave == 0 || wave == 3) && tl_it < 64)                    \
             g_tl[TLK][wave == 3][tl_it][i] = (i) == 9 ? (long long)wall_clock64() : (long long)clock64(); \
+        if (TLK == 4 && blockIdx.x < 1024 && lane == 0 && wave == 0 && tl_it >= 8 && tl_it < 24 && (i) < 16) \
+            g_tl2[blockIdx.x][tl_it - 8][i] = (long long)clock64();                                    \
     } while (0)
+#define TLHOOK(base) [&](int i) { if ((base) + i < 24 && ((base) == 10 || i < 6)) TL((base) + i); }
 #else
 #define TL(i) do { } while (0)
+#define TLHOOK(base) [](int) {}
 #endif
 
 // Persistent: each workgroup walks the bands of lattices blockIdx.x, blockIdx.x + gridDim.x, ...
@@ -235,6 +249,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
 #ifdef IDM_TIMELINE
     constexpr int TLK = MODE1 == M1_FIRST ? 0 : MODE1 == M1_PLAIN ? (CA == 32 ? 1 : 2) : (CA == 128 ? 3 : 4);
     int tl_it = 0;
+    if (TLK == 4 && blockIdx.x < 1024 && tid == 0) {
+        g_hw[blockIdx.x][0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+        g_hw[blockIdx.x][1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    }
 #endif
 
     // LDS map: [input region | mid tile | epilogue constants | score tile (HEAD)]; the output staging
@@ -405,21 +423,39 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
 
         // ---- conv1 on rows y0-1 .. y0+R (clipped to the map) -> mid tile row (g - (y0-1)) ----
         {
+#ifdef IDM_TIMELINE
+            int tl_epi = 0;
+#endif
             auto epi1 = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *kt, int mt, int r, int x, bool valid) {
                 if (!valid) return;
                 char *dst = lds_mid + __mul24(__mul24(r, W + 2) + x + 1, SM) + (mt * 32 + 4 * h) * 2;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+#ifdef IDM_EPI_SCALAR
+                    float z[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        z[i] = silu1(acc[4 * g + i] + kb[g][i]);
+                        if constexpr (TADD) z[i] += kt[g][i];
+                    }
+#else
                     f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                     z = silu4(z + kb[g]);
                     if constexpr (TADD) z = z + kt[g];
+#endif
                     *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
+#ifdef IDM_TIMELINE
+                    if (tl_epi == 0) TL(24 + g);
+#endif
                 }
+#ifdef IDM_TIMELINE
+                ++tl_epi;
+#endif
             };
             if constexpr (MODE1 == M1_FIRST)
                 conv_first_stage((const float *)lds_in, c_b1, W, rlo, (rhi - rlo) * W, (const bf16x8 *)a.w1, wave, lane, epi1);
             else
-                cs1.run(epi1);
+                cs1.run(epi1, TLHOOK(10));
         }
         float zq[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (EPI2 == E2_HEAD) {
@@ -464,17 +500,25 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
         if constexpr (EPI2 == E2_HEAD) {
             auto epi2 = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *kw, int mt, int r, int x, bool valid) {
                 (void)mt;
+#ifdef IDM_EPI_SCALAR
+                float p4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) p4[i] += silu1(acc[4 * g + i] + kb[g][i]) * kw[g][i];
+#else
                 f32x4 p4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                     p4 += silu4(z + kb[g]) * kw[g];
                 }
+#endif
                 float part = (p4[0] + p4[1]) + (p4[2] + p4[3]);
                 part += __shfl_xor(part, 32, 64);
                 if (valid && h == 0) score_s[r * W + x] = part + c_bh[0];
             };
-            cs2.run(epi2);
+            cs2.run(epi2, TLHOOK(18));
             TL(5);
             conv1_begin(nxt);
             if constexpr (!EARLY_PF) {
@@ -534,12 +578,18 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
                 char *dst = stage + __mul24(__mul24(r, W) + x, SO) + (mt * 32 + 4 * h) * 2;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+#ifdef IDM_EPI_SCALAR
+                    float z[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) z[i] = silu1(acc[4 * g + i] + kb[g][i]);
+#else
                     f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                     z = silu4(z + kb[g]);
+#endif
                     *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
                 }
             };
-            cs2.run(epi2);
+            cs2.run(epi2, TLHOOK(18));
             TL(5);
             conv1_begin(nxt);
             if constexpr (!EARLY_PF) pf_load(nxt);
@@ -661,7 +711,11 @@ struct LaunchState {
 template <class K>
 static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int64_t B, hipStream_t s, int threads = WG)
 {
+#ifdef IDM_EXP_ONE_WG   // timing experiment: LDS request padded so that one workgroup fits a CU
+    const int lds = std::max(a.lds_in_bytes + a.lds_mid_bytes, 84 * 1024);
+#else
     const int lds = a.lds_in_bytes + a.lds_mid_bytes;
+#endif
     if (!st.configured) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;

@@ -10,6 +10,14 @@ namespace {
 
 constexpr int WG = 256;
 
+// The convolution bias is the initial value of the accumulators (the first MFMA of a tile takes it as its C operand),
+// so the epilogues do not add it.  IDM_NO_BIAS_IN_ACC restores the add in the epilogue (comparison builds).
+#ifdef IDM_NO_BIAS_IN_ACC
+constexpr bool BIAS_IN_ACC = false;
+#else
+constexpr bool BIAS_IN_ACC = true;
+#endif
+
 #ifndef IDM_FRAG_DEPTH
 #define IDM_FRAG_DEPTH 1
 #endif
@@ -151,8 +159,9 @@ DEVI LaneGeo make_geo(int W, int li)
 // does the rest.
 //   PLAIN part: operand at  tile + ((row + ky)*(W+2) + col + kx)*S + 32*cg
 //   UP part:    the same on the half-resolution tile at row (row+ky)>>1, column (col+kx+1)>>1
-// Epilogue constants: c0 (bias) and, when HAS_C1, a second per-cout array c1 live in LDS as float32;
-// the 16 values a lane needs per cout tile are read during the last superstep and handed to epi().
+// Epilogue constants: c0 (bias) and, when HAS_C1, a second per-cout array c1 live in LDS as float32.  The 16 bias values a
+// lane needs per cout tile are read before the first superstep and start the accumulators; the 16 of c1 are read during the
+// last superstep.  Both are handed to epi(), whose accumulator already includes the bias.
 template <int CA, int CB, bool UP, int COUT, int NT, int MS, int WD, bool HAS_C1>
 struct ConvStage {
     static constexpr int MTOT = COUT / 32, NSL = MTOT / MS;
@@ -288,13 +297,20 @@ struct ConvStage {
         }
         (void)a_pl; (void)a_up; (void)a_b; (void)c_up;
 
+        f32x4 k0[MS][4], k1[MS][4];
+        if constexpr (BIAS_IN_ACC) {
+#pragma unroll
+            for (int m = 0; m < MS; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) k0[m][q] = *(const f32x4 *)(c0 + (sl * MS + m) * 32 + 8 * q + 4 * h);
+        }
         f32x16 acc[MS][N];
 #pragma unroll
         for (int m = 0; m < MS; ++m)
 #pragma unroll
             for (int n = 0; n < N; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = BIAS_IN_ACC ? k0[m][r >> 2][r & 3] : 0.0f;
 
         // activation fragments are read FD supersteps ahead of their MFMAs (LDS latency under load exceeds the MFMA time
         // of a superstep with few tiles)
@@ -315,7 +331,6 @@ struct ConvStage {
                 }
             }
         };
-        f32x4 k0[MS][4], k1[MS][4];
         if constexpr (!HAS_C1) {
 #pragma unroll
             for (int m = 0; m < MS; ++m)
@@ -346,7 +361,7 @@ struct ConvStage {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int co = (sl * MS + m) * 32 + 8 * q + 4 * h;
-                        k0[m][q] = *(const f32x4 *)(c0 + co);
+                        if constexpr (!BIAS_IN_ACC) k0[m][q] = *(const f32x4 *)(c0 + co);
                         if constexpr (HAS_C1) k1[m][q] = *(const f32x4 *)(c1 + co);
                     }
             }

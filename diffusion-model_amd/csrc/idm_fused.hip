@@ -83,7 +83,7 @@ DEVI void conv_first_stage(const float *xs, const float *c0, int W, int r0, int 
         }
         f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        for (int i = 0; i < 16; ++i) acc[i] = BIAS_IN_ACC ? k0[i >> 2][i & 3] : 0.0f;
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hi, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, lo, acc, 0, 0, 0);
         epi(acc, k0, k1, 0, r, x, valid);
@@ -435,12 +435,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
                     float z[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        z[i] = silu1(acc[4 * g + i] + kb[g][i]);
+                        z[i] = silu1(BIAS_IN_ACC ? acc[4 * g + i] : acc[4 * g + i] + kb[g][i]);
                         if constexpr (TADD) z[i] += kt[g][i];
                     }
 #else
                     f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                    z = silu4(z + kb[g]);
+                    z = silu4(BIAS_IN_ACC ? z : z + kb[g]);
                     if constexpr (TADD) z = z + kt[g];
 #endif
                     *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
@@ -505,13 +505,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) p4[i] += silu1(acc[4 * g + i] + kb[g][i]) * kw[g][i];
+                    for (int i = 0; i < 4; ++i) p4[i] += silu1(BIAS_IN_ACC ? acc[4 * g + i] : acc[4 * g + i] + kb[g][i]) * kw[g][i];
 #else
                 f32x4 p4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                    p4 += silu4(z + kb[g]) * kw[g];
+                    p4 += silu4(BIAS_IN_ACC ? z : z + kb[g]) * kw[g];
                 }
 #endif
                 float part = (p4[0] + p4[1]) + (p4[2] + p4[3]);
@@ -581,10 +581,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
 #ifdef IDM_EPI_SCALAR
                     float z[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) z[i] = silu1(acc[4 * g + i] + kb[g][i]);
+                    for (int i = 0; i < 4; ++i) z[i] = silu1(BIAS_IN_ACC ? acc[4 * g + i] : acc[4 * g + i] + kb[g][i]);
 #else
                     f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                    z = silu4(z + kb[g]);
+                    z = silu4(BIAS_IN_ACC ? z : z + kb[g]);
 #endif
                     *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
                 }

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                    p4 += silu4(z + kb[g]) * kw[g];
+                    p4 += silu4(BIAS_IN_ACC ? z : z + kb[g]) * kw[g];
                 }
                 float part = (p4[0] + p4[1]) + (p4[2] + p4[3]);
                 part += __shfl_xor(part, 32, 64);
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                    z = silu4(z + kb[g]);
+                    z = silu4(BIAS_IN_ACC ? z : z + kb[g]);
                     if constexpr (TADD) z = z + kt[g];
                     *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
                 }

@@ -225,13 +225,28 @@ struct ConvStage {
 
     // up_row_bias: parity of the global row of window row 0 (UP part): the half-resolution window row of
     // full-resolution window row r is (r + up_row_bias) >> 1.
+    // Single-slice stages fetch the same first weights in every run: arm() requests them ahead of time (the ring is free
+    // as soon as a run's last MFMA has been issued), and the begin() that follows is told so.  set_weights() fixes the
+    // weight tensor once, in uniform control flow: were the buffer resource reassigned inside the band loop's branches,
+    // the compiler would keep it in vector registers and wrap every fetch in a readfirstlane loop.
+    DEVI void set_weights(const bf16x8 *w, int lane)
+    {
+        wrsrc = make_rsrc(w, 9u * (CA + CB) * COUT * 2u);
+        wlane = (unsigned)lane;
+    }
+    DEVI void arm()
+    {
+        static_assert(NSL == 1, "arm() is for stages with a single cout slice");
+        set_slice(0);
+        prologue();
+    }
+
     DEVI void begin(const char *la, const char *lb, const float *c0_, const float *c1_, const LaneGeo &geo, int r0_,
-                    int nrows_, const bf16x8 *w, int wave, int lane, int up_row_bias = 0, int nwaves = 4)
+                    int nrows_, const bf16x8 *w, int wave, int lane, int up_row_bias = 0, int nwaves = 4, bool armed = false)
     {
         up_rb = up_row_bias;
         lds_a = la; lds_b = lb; c0 = c0_; c1 = c1_; g = geo; h = lane >> 5; r0 = r0_; nrows = nrows_;
-        wrsrc = make_rsrc(w, 9u * (CA + CB) * COUT * 2u);
-        wlane = (unsigned)lane;
+        if (!armed) set_weights(w, lane);   // (armed: set_weights() was called once, see there)
         Rh = (nrows + g.TR - 1) / g.TR;
         const int tot = NSL * g.ncb * Rh;
         f = (wave * tot) / nwaves;
@@ -242,7 +257,7 @@ struct ConvStage {
                 prologue();
                 loaded = true;
             }
-        } else if (f < f1) {
+        } else if (f < f1 && !armed) {
             set_slice(unit_of(f) % NSL);
             prologue();
         }
@@ -447,5 +462,90 @@ struct ConvStage {
         }
     }
 };
+
+// Register-held payload of one LDS input tile: NP 16-byte items per thread (item i = tid + k*WGS
+// covers row i / (W*C/8), 8 channels).  load() reads rows [g0, g0+nrows) of a global NHWC bf16 map
+// (zeros outside [0,Hmap)); store() writes them into the tile (row t = global row g0+t) and clears
+// (unless HALO is false) the tile's two halo columns.  Splitting the two lets the loads of the next band fly while the
+// current band is still being computed.
+template <int C, int NP, int WGS = WG>
+struct TileRegs {
+    static constexpr int S = C * 2 + 16, CH = C / 8;
+    bf16x8 v[NP];
+
+    // src: this lattice's map (Hmap rows); rows outside it, and items beyond the tile, read as zero
+    // through the buffer range check (their offsets wrap to >= 2^31).
+    DEVI void load(const __bf16 *__restrict__ src, int Hmap, int W, int g0, int nrows, int tid)
+    {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, (unsigned)(Hmap * W * C * 2));
+        const int ipr = W * CH;
+        int row = tid / ipr, rem = tid - row * ipr;
+        const int drow = WGS / ipr, drem = WGS - drow * ipr;
+        if (drem == 0) {  // a thread's items share one tile column: rows step by drow, offsets by a constant
+            const int off0 = ((g0 + row) * ipr + rem) * 16;
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+                v[k] = buf_load16(rs, row + k * drow < nrows ? (unsigned)(off0 + k * drow * ipr * 16) : 0x80000000u, 0);
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int off = ((g0 + row) * ipr + rem) * 16;
+            v[k] = buf_load16(rs, row < nrows ? (unsigned)off : 0x80000000u, 0);
+            rem += drem;
+            row += drow;
+            if (rem >= ipr) { rem -= ipr; ++row; }
+        }
+    }
+
+    template <bool HALO = true>
+    DEVI void store(char *tile, int W, int nrows, int tid) const
+    {
+        const int ipr = W * CH;
+        int row = tid / ipr, rem = tid - row * ipr;
+        const int drow = WGS / ipr, drem = WGS - drow * ipr;
+        if (drem == 0) {
+            char *p0 = tile + (row * (W + 2) + rem / CH + 1) * S + (rem % CH) * 16;
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+                if (row + k * drow < nrows) *(bf16x8 *)(p0 + k * drow * (W + 2) * S) = v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if (row < nrows) *(bf16x8 *)(tile + (row * (W + 2) + rem / CH + 1) * S + (rem % CH) * 16) = v[k];
+                rem += drem;
+                row += drow;
+                if (rem >= ipr) { rem -= ipr; ++row; }
+            }
+        }
+        if constexpr (HALO) {
+            bf16x8 z;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f;
+            for (int i = tid; i < nrows * 2 * CH; i += WGS) {
+                const int ch = i % CH, side = (i / CH) & 1, r = i / (2 * CH);
+                *(bf16x8 *)(tile + (r * (W + 2) + side * (W + 1)) * S + ch * 16) = z;
+            }
+        }
+    }
+};
+
+// Zeroes the halo columns of rows [0,nrows) and the whole of rows [z0,z1) of an LDS tile.
+template <int C, int WGS = WG>
+DEVI void clear_halo(char *tile, int W, int nrows, int z0, int z1, int tid)
+{
+    constexpr int S = C * 2 + 16, CH = C / 8;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < nrows * 2 * CH; i += WGS) {
+        const int ch = i % CH, side = (i / CH) & 1, r = i / (2 * CH);
+        *(f32x4 *)(tile + (r * (W + 2) + side * (W + 1)) * S + ch * 16) = z;
+    }
+    if (z1 > z0) {
+        char *p = tile + z0 * (W + 2) * S;
+        const int bytes = (z1 - z0) * (W + 2) * S;  // S is a multiple of 16
+        for (int i = tid * 16; i < bytes; i += WGS * 16) *(f32x4 *)(p + i) = z;
+    }
+}
+
 
 }  // namespace

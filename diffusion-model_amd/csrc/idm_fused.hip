@@ -41,6 +41,7 @@
 #include "idm_conv_stage.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -87,90 +88,6 @@ DEVI void conv_first_stage(const float *xs, const float *c0, int W, int r0, int 
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hi, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, lo, acc, 0, 0, 0);
         epi(acc, k0, k1, 0, r, x, valid);
-    }
-}
-
-// Register-held payload of one LDS input tile: NP 16-byte items per thread (item i = tid + k*WGS
-// covers row i / (W*C/8), 8 channels).  load() reads rows [g0, g0+nrows) of a global NHWC bf16 map
-// (zeros outside [0,Hmap)); store() writes them into the tile (row t = global row g0+t) and clears
-// (unless HALO is false) the tile's two halo columns.  Splitting the two lets the loads of the next band fly while the
-// current band is still being computed.
-template <int C, int NP, int WGS = WG>
-struct TileRegs {
-    static constexpr int S = C * 2 + 16, CH = C / 8;
-    bf16x8 v[NP];
-
-    // src: this lattice's map (Hmap rows); rows outside it, and items beyond the tile, read as zero
-    // through the buffer range check (their offsets wrap to >= 2^31).
-    DEVI void load(const __bf16 *__restrict__ src, int Hmap, int W, int g0, int nrows, int tid)
-    {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(src, (unsigned)(Hmap * W * C * 2));
-        const int ipr = W * CH;
-        int row = tid / ipr, rem = tid - row * ipr;
-        const int drow = WGS / ipr, drem = WGS - drow * ipr;
-        if (drem == 0) {  // a thread's items share one tile column: rows step by drow, offsets by a constant
-            const int off0 = ((g0 + row) * ipr + rem) * 16;
-#pragma unroll
-            for (int k = 0; k < NP; ++k)
-                v[k] = buf_load16(rs, row + k * drow < nrows ? (unsigned)(off0 + k * drow * ipr * 16) : 0x80000000u, 0);
-            return;
-        }
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int off = ((g0 + row) * ipr + rem) * 16;
-            v[k] = buf_load16(rs, row < nrows ? (unsigned)off : 0x80000000u, 0);
-            rem += drem;
-            row += drow;
-            if (rem >= ipr) { rem -= ipr; ++row; }
-        }
-    }
-
-    template <bool HALO = true>
-    DEVI void store(char *tile, int W, int nrows, int tid) const
-    {
-        const int ipr = W * CH;
-        int row = tid / ipr, rem = tid - row * ipr;
-        const int drow = WGS / ipr, drem = WGS - drow * ipr;
-        if (drem == 0) {
-            char *p0 = tile + (row * (W + 2) + rem / CH + 1) * S + (rem % CH) * 16;
-#pragma unroll
-            for (int k = 0; k < NP; ++k)
-                if (row + k * drow < nrows) *(bf16x8 *)(p0 + k * drow * (W + 2) * S) = v[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                if (row < nrows) *(bf16x8 *)(tile + (row * (W + 2) + rem / CH + 1) * S + (rem % CH) * 16) = v[k];
-                rem += drem;
-                row += drow;
-                if (rem >= ipr) { rem -= ipr; ++row; }
-            }
-        }
-        if constexpr (HALO) {
-            bf16x8 z;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.0f;
-            for (int i = tid; i < nrows * 2 * CH; i += WGS) {
-                const int ch = i % CH, side = (i / CH) & 1, r = i / (2 * CH);
-                *(bf16x8 *)(tile + (r * (W + 2) + side * (W + 1)) * S + ch * 16) = z;
-            }
-        }
-    }
-};
-
-// Zeroes the halo columns of rows [0,nrows) and the whole of rows [z0,z1) of an LDS tile.
-template <int C, int WGS = WG>
-DEVI void clear_halo(char *tile, int W, int nrows, int z0, int z1, int tid)
-{
-    constexpr int S = C * 2 + 16, CH = C / 8;
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (int i = tid; i < nrows * 2 * CH; i += WGS) {
-        const int ch = i % CH, side = (i / CH) & 1, r = i / (2 * CH);
-        *(f32x4 *)(tile + (r * (W + 2) + side * (W + 1)) * S + ch * 16) = z;
-    }
-    if (z1 > z0) {
-        char *p = tile + z0 * (W + 2) * S;
-        const int bytes = (z1 - z0) * (W + 2) * S;  // S is a multiple of 16
-        for (int i = tid * 16; i < bytes; i += WGS * 16) *(f32x4 *)(p + i) = z;
     }
 }
 
@@ -775,7 +692,18 @@ hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
         case FK_M1: return launch_one(st[6], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1, 16, 8>, a, B, s);
         case FK_M2: return launch_one(st[7], fused2_kernel<M1_PLAIN, 64, 0, 128, 128, E2_STORE, true, IDM_CFG_M2, 8, 8>, a, B, s);
         case FK_M3: return launch_one(st[8], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, IDM_CFG_M3, 16, 16, IDM_M3_WAVES>, a, B, s, IDM_M3_WAVES * 64);
-        default: return launch_one(st[9], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, IDM_CFG_B, 32, IDM_B_WAVES == 8 ? 16 : 8, IDM_B_WAVES>, a, B, s, IDM_B_WAVES * 64);
+        default: {
+            // ISINGDIFF_B_SPLIT=1 (or a build with -DIDM_FUSED_B_SPLIT) selects the schedule of idm_fused_split.hip: the same
+            // results bit for bit, MFMA and non-MFMA work on separate wavefronts; slower than the two-workgroup schedule
+            // so far, kept for the comparison.
+#ifdef IDM_FUSED_B_SPLIT
+            static const bool split = true;
+#else
+            static const bool split = [] { const char *e = getenv("ISINGDIFF_B_SPLIT"); return e && e[0] == '1'; }();
+#endif
+            if (split) return launch_b_split(a, B, s);
+            return launch_one(st[9], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, IDM_CFG_B, 32, IDM_B_WAVES == 8 ? 16 : 8, IDM_B_WAVES>, a, B, s, IDM_B_WAVES * 64);
+        }
         }
     }
     switch (kind) {

@@ -410,3 +410,29 @@ def test_bf16_update_is_the_canonical_expression_of_its_score(gpu_real, L):
         want = (c1 * x + beta * sc) + z[0] * sd       # numpy float32: one rounding per operation
         assert want.dtype == np.float32
         assert np.array_equal(new.view(np.uint32), want.view(np.uint32))
+
+
+def test_split_schedule_of_fused_b_is_bit_identical(gpu_real, tmp_path):
+    """ISINGDIFF_B_SPLIT=1 runs conv8 / conv9 / head / update of the L=32 bf16 sampler with MFMA and non-MFMA work on
+    separate wavefronts (two lattices in flight per workgroup); the arithmetic is the fused kernel's, so the final state
+    must be the same bit for bit.  Odd and small batches cover workgroups whose second lattice stream runs dry.  (The
+    switch is read once per process, hence the child process.)"""
+    import os, subprocess, sys
+    from isingdiff.sampler import sample, beta_schedule
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {os.path.join(root, 'diffusion-model_amd')!r})\n"
+        "from isingdiff import load_model, sample, beta_schedule\n"
+        f"m = load_model({os.path.join(root, 'weights', 'b_diffusion_model_2d_ising_realspace_unet.keras')!r}, device=0, precision='bf16')\n"
+        "for B in (1, 5, 777):\n"
+        "    r = sample(m, B, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision='bf16', keep_state=True)\n"
+        "    np.save(os.path.join(sys.argv[1], f'x{B}.npy'), r.x_final.cpu().numpy())\n")
+    env = dict(os.environ, ISINGDIFF_B_SPLIT="1")
+    subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, env=env, timeout=240)
+    assert os.environ.get("ISINGDIFF_B_SPLIT") != "1"
+    for B in (1, 5, 777):
+        want = sample(gpu_real, B, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision="bf16", keep_state=True)
+        got = np.load(tmp_path / f"x{B}.npy")
+        assert np.isfinite(got).all()
+        assert np.array_equal(got, want.x_final.cpu().numpy()), B

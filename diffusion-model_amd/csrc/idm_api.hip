@@ -251,9 +251,9 @@ Plan make_plan(const idm_model *m, int H, int W, int precision)
     p.layers = false;
     if (precision == IDM_BF16 && !p.fused && m->use_fused && (m->C == 2 || m->bn)) {
         const int hh[3] = {p.Hp, p.Hp / 2, p.Hp / 4}, ww[3] = {p.Wp, p.Wp / 2, p.Wp / 4};
-        const int lvl[SK_COUNT] = {0, 1, 1, 2, 2, 1, 1, 0, 0, 0};
+        const int lvl[SK_COUNT] = {0, 1, 1, 2, 2, 1, 1, 0, 0, 0, 0};
         p.layers = true;
-        for (int sk = SK_CONV1; sk <= SK_CONV9S; ++sk) {
+        for (int sk = SK_CONV1; sk < SK_COUNT; ++sk) {
             if (sk == SK_CONV9) continue;
             p.sR[sk] = pick_strip_rows(sk, hh[lvl[sk]], ww[lvl[sk]], &p.sWS[sk]);
             if (p.sR[sk] == 0) p.layers = false;
@@ -524,7 +524,8 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
 
     const double npx = (double)Bc * Hp * Wp;
     timed(m, "conv_first", 2.0 * 9 * m->C * F * npx, (double)Bc * p.H * p.W * m->C * 4 + npx * F * p.es, s, [&] {
-        launch_conv_first(x, Bc, p.H, p.W, Hp, Wp, m->C, m->w_first, m->bias[0], m->scale[0], m->shift[0], a0, F, bf, s);
+        if (bf) launch_conv_first_bf16(x, Bc, p.H, p.W, Hp, Wp, m->C, m->w_first, m->bias[0], m->scale[0], m->shift[0], a0, s);
+        else launch_conv_first(x, Bc, p.H, p.W, Hp, Wp, m->C, m->w_first, m->bias[0], m->scale[0], m->shift[0], a0, F, false, s);
     });
 
     auto conv = [&](int layer, const void *in0, const void *in1, int C0, int C1, int H, int W, int mode, void *out,
@@ -545,9 +546,12 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
         // layers 1..9 as strip kernels (BatchNorm folded into weights and bias); pooled maps live in the
         // buffers of layers that run later (a4 before conv4, a5 before conv5)
         int rc = IDM_OK;
+        // the two-channel head of the spectral model rides in conv9's epilogue unless the caller wants conv9's map itself
+        const bool fuse_head = m->C == 2 && !taps;
         auto strip = [&](int sk, int l, const void *in_a, const void *in_b, void *out, void *out_pool, int H, int W) {
             if (rc != IDM_OK) return;
             StripArgs a = {};
+            if (sk == SK_CONV9H2) { a.w_head = m->w_head; a.b_head = m->bias[10]; a.score_out = score; }
             a.H = H; a.W = W; a.R = p.sR[sk]; a.WS = p.sWS[sk]; a.nbands = H / a.R; a.nstrips = W / a.WS;
             a.Hx = p.H; a.Wx = p.W; a.B = Bc;
             a.in_a = in_a; a.in_b = in_b;
@@ -572,10 +576,12 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
         strip(SK_CONV6, 6, a5, s2, a6, nullptr, Hp / 2, Wp / 2);
         strip(SK_CONV7, 7, a6, nullptr, a7, nullptr, Hp / 2, Wp / 2);
         strip(SK_CONV8, 8, a7, s1, a8, nullptr, Hp, Wp);
-        strip(SK_CONV9S, 9, a8, nullptr, a9, nullptr, Hp, Wp);
+        if (fuse_head) strip(SK_CONV9H2, 9, a8, nullptr, nullptr, nullptr, Hp, Wp);
+        else strip(SK_CONV9S, 9, a8, nullptr, a9, nullptr, Hp, Wp);
         if (rc != IDM_OK) return rc;
-        timed(m, "head", 2.0 * F * m->C * Bc * p.H * p.W, (double)Bc * p.H * p.W * (F * 2 + m->C * 4), s,
-              [&] { launch_head_bf16(a9, Bc, p.H, p.W, Hp, Wp, F, m->C, m->w_head, m->bias[10], score, s); });
+        if (!fuse_head)
+            timed(m, "head", 2.0 * F * m->C * Bc * p.H * p.W, (double)Bc * p.H * p.W * (F * 2 + m->C * 4), s,
+                  [&] { launch_head_bf16(a9, Bc, p.H, p.W, Hp, Wp, F, m->C, m->w_head, m->bias[10], score, s); });
     } else {
     conv(1, a0, nullptr, F, 0, Hp, Wp, CONV_PLAIN, s1, nullptr, false);
     conv(2, s1, nullptr, F, 0, Hp / 2, Wp / 2, CONV_POOL, a2, nullptr, false);

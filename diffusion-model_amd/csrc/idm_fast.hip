@@ -115,3 +115,59 @@ void launch_conv_bf16(const ConvArgs &a, hipStream_t s)
     default: launch_conv_bf16_mt<4>(a, s); break;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// First layer (C -> 32 channels, C = 1 or 2) with bf16 output: reads the unpadded float32 state (B,H,W,C), writes the
+// padded map (B,Hp,Wp,32).  One thread per pixel (the taps are read once), hardware exp / rcp in the activation, four
+// 16-byte stores per pixel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__restrict__ x, int64_t B, int H, int W, int Hp, int Wp,
+                                                              int C, const float *__restrict__ w, const float *__restrict__ bias,
+                                                              const float *__restrict__ scale, const float *__restrict__ shift,
+                                                              __bf16 *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float ws[9 * 2 * 32];
+    __shared__ __attribute__((aligned(16))) float bs[3 * 32];
+    for (int i = threadIdx.x; i < 9 * C * 32; i += 256) ws[i] = w[i];
+    if (threadIdx.x < 32) {
+        bs[threadIdx.x] = bias[threadIdx.x];
+        bs[32 + threadIdx.x] = scale ? scale[threadIdx.x] : 1.0f;
+        bs[64 + threadIdx.x] = shift ? shift[threadIdx.x] : 0.0f;
+    }
+    __syncthreads();
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= B * Hp * Wp) return;
+    const int xo = (int)(p % Wp), yo = (int)((p / Wp) % Hp);
+    const int64_t b = p / ((int64_t)Wp * Hp);
+    float acc[32];
+#pragma unroll
+    for (int f = 0; f < 32; ++f) acc[f] = 0.0f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = yo + tap / 3 - 1, xx = xo + tap % 3 - 1;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;   // outside the map, or in its zero padding
+        for (int c = 0; c < C; ++c) {
+            const float v = x[((b * H + yy) * W + xx) * C + c];
+            const float *wr = ws + (tap * C + c) * 32;
+#pragma unroll
+            for (int f = 0; f < 32; ++f) acc[f] = fmaf(v, wr[f], acc[f]);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bf16x8 o;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const float z = (acc[8 * g + f] + bs[8 * g + f]) * bs[32 + 8 * g + f] + bs[64 + 8 * g + f];
+            o[f] = (__bf16)(z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f)));
+        }
+        *(bf16x8 *)(out + p * 32 + 8 * g) = o;
+    }
+}
+
+void launch_conv_first_bf16(const float *x, int64_t B, int H, int W, int Hp, int Wp, int C, const float *w, const float *bias,
+                            const float *scale, const float *shift, void *out, hipStream_t s)
+{
+    const unsigned grid = (unsigned)((B * Hp * Wp + 255) / 256);
+    hipLaunchKernelGGL(conv_first_bf16_kernel, dim3(grid), dim3(256), 0, s, x, B, H, W, Hp, Wp, C, w, bias, scale, shift,
+                       (__bf16 *)out);
+}

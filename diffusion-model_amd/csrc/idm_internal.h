@@ -58,6 +58,9 @@ struct PhiloxArgs {
 
 // ---- float32 canonical-order kernels (idm_canon.hip) ----
 void launch_conv_f32(const ConvArgs &a, hipStream_t s);
+// bf16 output, one thread per pixel and 8 channels (idm_fast.hip)
+void launch_conv_first_bf16(const float *x, int64_t B, int H, int W, int Hp, int Wp, int C, const float *w, const float *bias,
+                            const float *scale, const float *shift, void *out, hipStream_t s);
 void launch_conv_first(const float *x, int64_t B, int H, int W, int Hp, int Wp, int C, const float *w,
                        const float *bias, const float *scale, const float *shift, void *out, int F,
                        bool out_bf16, hipStream_t s);
@@ -125,7 +128,7 @@ hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s);
 hipError_t launch_b_split(const FusedArgs &a, int64_t B, hipStream_t s);
 
 // ---- single-convolution band/strip kernels (idm_strip.hip) ----
-enum StripKindId { SK_CONV1 = 0, SK_CONV2, SK_CONV3, SK_CONV4, SK_CONV5, SK_CONV6, SK_CONV7, SK_CONV8, SK_CONV9, SK_CONV9S, SK_COUNT };   // SK_CONV9: conv9 + head + update; SK_CONV9S: conv9 stored
+enum StripKindId { SK_CONV1 = 0, SK_CONV2, SK_CONV3, SK_CONV4, SK_CONV5, SK_CONV6, SK_CONV7, SK_CONV8, SK_CONV9, SK_CONV9S, SK_CONV9H2, SK_COUNT };   // SK_CONV9: conv9 + head + update; SK_CONV9S: conv9 stored; SK_CONV9H2: conv9 + two-channel head
 
 struct StripArgs {
     int H, W;          // map size of this layer's output (= its full-resolution input)
@@ -140,7 +143,7 @@ struct StripArgs {
     void *out_pool;    // POOL: (B,H/2,W/2,COUT) bf16
     const float *w_head, *b_head;
     float *x;
-    float *score_out;
+    float *score_out;  // HEAD: (B,Hx,Wx); two-channel head: (B,Hx,Wx,2)
     const float *noise;
     float c1, beta, sd;
     int add_noise, do_update;

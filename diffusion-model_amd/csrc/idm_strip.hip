@@ -12,7 +12,7 @@
 
 namespace {
 
-enum { SE_STORE = 0, SE_STORE_POOL = 1, SE_HEAD = 2 };
+enum { SE_STORE = 0, SE_STORE_POOL = 1, SE_HEAD = 2, SE_HEAD2 = 3 };   // SE_HEAD2: 1x1 head with two output channels, score only
 
 // Register-held payload of one LDS input window: NP 16-byte items per thread (item i = tid + k*WG:
 // row i / (ncols*C/8), then column, then 8-channel group).  load() reads rows [g0, g0+nrows) x
@@ -80,18 +80,22 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
     char *tile_a = smem;
     char *tile_b = UP ? smem + ((((R >> 1) + 2) * ((WS >> 1) + 2) * SA + 15) & ~15) : nullptr;
     char *stage = smem + a.lds_in_bytes;
-    constexpr int NCONST = 2 * COUT + 4;
+    // constants: bias | second per-channel array (head weights / time add) | head bias (4 floats) | second head vector
     float *cst = (float *)(smem + a.lds_in_bytes + a.lds_stage_bytes);
-    const float *c_b = cst, *c_2 = cst + COUT, *c_bh = cst + 2 * COUT;
-    (void)c_bh; (void)NCONST;
+    const float *c_b = cst, *c_2 = cst + COUT, *c_bh = cst + 2 * COUT, *c_3 = cst + 2 * COUT + 4;
+    (void)c_bh; (void)c_3;
     for (int i = tid; i < COUT; i += WG) {
         cst[i] = a.bias[i];
-        cst[COUT + i] = EPI == SE_HEAD ? a.w_head[i] : (TADD ? a.tadd[i] : 0.0f);
+        cst[COUT + i] = EPI == SE_HEAD ? a.w_head[i] : EPI == SE_HEAD2 ? a.w_head[2 * i] : (TADD ? a.tadd[i] : 0.0f);
+        cst[2 * COUT + 4 + i] = EPI == SE_HEAD2 ? a.w_head[2 * i + 1] : 0.0f;
     }
-    if (tid == 0) cst[2 * COUT] = EPI == SE_HEAD ? a.b_head[0] : 0.0f;
+    if (tid == 0) {
+        cst[2 * COUT] = EPI == SE_HEAD || EPI == SE_HEAD2 ? a.b_head[0] : 0.0f;
+        cst[2 * COUT + 1] = EPI == SE_HEAD2 ? a.b_head[1] : 0.0f;
+    }
 
     const LaneGeo geo = make_geo(WS, lane & 31);
-    using Conv = ConvStage<CA, CB, UP, COUT, NT, MS, WD, TADD || EPI == SE_HEAD>;
+    using Conv = ConvStage<CA, CB, UP, COUT, NT, MS, WD, TADD || EPI == SE_HEAD || EPI == SE_HEAD2>;
     Conv cs;
 
     WinRegs<CA, NPA> ra;
@@ -221,6 +225,37 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
                     *(f32x4 *)(a.x + q.off) = xv;
                 }
             }
+        } else if constexpr (EPI == SE_HEAD2) {
+            // conv9 + the two-channel 1x1 head of the spectral model: the score leaves as (Re, Im) pairs, cropped to the
+            // unpadded spectrum; the state update stays a kernel of its own
+            float *score_s = (float *)stage;   // [rows][WS][2]
+            auto epi = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *kw, int mt, int r, int x, bool valid) {
+                (void)mt;
+                f32x4 pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                    z = silu4(BIAS_IN_ACC ? z : z + kb[g]);
+                    pa += z * kw[g];
+                    pb += z * *(const f32x4 *)(c_3 + 8 * g + 4 * h);
+                }
+                float sa = (pa[0] + pa[1]) + (pa[2] + pa[3]), sb = (pb[0] + pb[1]) + (pb[2] + pb[3]);
+                sa += __shfl_xor(sa, 32, 64);
+                sb += __shfl_xor(sb, 32, 64);
+                if (valid && h == 0) *(f32x2 *)(score_s + (r * WS + x) * 2) = f32x2{sa + c_bh[0], sb + c_bh[1]};
+            };
+            cs.run(epi);
+            conv_begin(wg_next);
+            pf_load(wg_next);
+            __syncthreads();
+            const int rowsx = min(rows, a.Hx - y0), colsx = min(WS, a.Wx - x0);
+            if (rowsx > 0 && colsx > 0) {
+                float *sg = a.score_out + (((int64_t)b * a.Hx + y0) * a.Wx + x0) * 2;
+                for (int i = tid; i < rowsx * colsx; i += WG) {
+                    const int r = i / colsx, xc = i - r * colsx;
+                    *(f32x2 *)(sg + ((int64_t)r * a.Wx + xc) * 2) = *(const f32x2 *)(score_s + (r * WS + xc) * 2);
+                }
+            }
         } else {
             auto epi = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *kt, int mt, int r, int x, bool valid) {
                 if (!valid) return;
@@ -283,6 +318,7 @@ constexpr StripKind kStrip[SK_COUNT] = {
     {64, 32, 1, 32, SE_STORE, 4, 6},       // SK_CONV8
     {32, 0, 0, 32, SE_HEAD, 6, 0},         // SK_CONV9 (+ head, update)
     {32, 0, 0, 32, SE_STORE, 6, 0},        // SK_CONV9S
+    {32, 0, 0, 32, SE_HEAD2, 6, 0},        // SK_CONV9H2 (+ two-channel head)
 };
 
 inline int a16(int v) { return (v + 15) & ~15; }
@@ -330,8 +366,8 @@ void strip_lds_bytes(int kind, int R, int WS, int *in_bytes, int *stage_bytes, i
     if (!k.up) in = (R + 2) * (WS + 2) * sa;
     else in = a16((R / 2 + 2) * (WS / 2 + 2) * sa) + (R + 2) * (WS + 2) * sb;
     *in_bytes = a16(in);
-    *stage_bytes = a16(k.epi == SE_HEAD ? R * WS * 4 : R * WS * so);
-    *const_bytes = (2 * k.cout + 4) * 4;
+    *stage_bytes = a16(k.epi == SE_HEAD ? R * WS * 4 : k.epi == SE_HEAD2 ? R * WS * 8 : R * WS * so);
+    *const_bytes = (3 * k.cout + 4) * 4;
 }
 
 // True when the next item's windows fit the instance's prefetch registers.
@@ -368,6 +404,7 @@ hipError_t launch_strip(int kind, const StripArgs &a, hipStream_t s)
     case SK_CONV7: return STRIP_INST(6, 4, 64, 0, false, 64, SE_STORE, false, 3, 1, IDM_STRIP_WD, 11, 0, 2);
     case SK_CONV8: return STRIP_INST(7, 8, 64, 32, true, 32, SE_STORE, false, 3, 1, IDM_STRIP_WD, 4, 6, 2);
     case SK_CONV9: return STRIP_INST(8, 8, 32, 0, false, 32, SE_HEAD, false, 3, 1, IDM_STRIP_WD, 6, 0, 2);
+    case SK_CONV9H2: return STRIP_INST(10, 8, 32, 0, false, 32, SE_HEAD2, false, 3, 1, IDM_STRIP_WD, 6, 0, 2);
     default: return STRIP_INST(9, 8, 32, 0, false, 32, SE_STORE, false, 3, 1, IDM_STRIP_WD, 6, 0, 2);
     }
 }

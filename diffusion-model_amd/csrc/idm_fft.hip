@@ -5,7 +5,7 @@
 // complex-to-real transform along axis 1 that ignores the imaginary parts of the k = 0 and k = L/2 columns.
 //
 // Every 1-D transform is a mixed-radix (4, 2, 3, 5) Cooley-Tukey FFT held entirely in the registers of one
-// thread (or of two neighbouring lanes that exchange halves through DPP for L = 64 / 128); loops are unrolled at
+// thread (or of two / four neighbouring lanes that exchange parts through DPP for L = 64 / 128); loops are unrolled at
 // compile time, so every twiddle index is a constant and the factors are scalar loads from the kernel argument.
 //     step 1  thread (lattice, column k): 1-D inverse FFT over the L rows, read straight from global memory
 //             (consecutive lanes read consecutive 8-byte (Re, Im) pairs), written to LDS as float64
@@ -126,7 +126,7 @@ DEVI void fft_inplace(cplx (&a)[NTOT], const cplx *__restrict__ tw)
         static_for<0, R>([&](auto k1c) { fft_inplace<M, L, BASE + decltype(k1c)::value * M, NTOT>(a, tw); });
 }
 
-// value of the neighbouring lane (lane ^ 1)
+// value of lane ^ 1 / lane ^ 2 (DPP quad permutes)
 DEVI double swap1(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -134,10 +134,28 @@ DEVI double swap1(double v)
     hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
+DEVI double swap2(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 
 // L-point inverse DFT whose input is dealt to SPLIT lanes (lane h holds x[SPLIT*i + h], i < N = L / SPLIT) and whose
-// output comes back as the block X[N*h + k], k < N, at slot fft_pos(N, k).  SPLIT = 2: each lane transforms its half, the
-// halves are swapped through DPP and X[k] = E[k] + w^k O[k], X[k + N] = E[k] - w^k O[k].
+// output comes back as the block X[N*hb + k], k < N, at slot fft_pos(N, k), hb = split_block<SPLIT>(h).
+//   SPLIT = 2: each lane transforms its half, the halves are swapped through DPP and X[k] = E[k] + w^k O[k],
+//              X[k + N] = E[k] - w^k O[k]; lane h keeps block h.
+//   SPLIT = 4: two such levels.  Lanes h and h ^ 2 (residues r and r + 2 mod 4) combine into the 2N-point transform G_r of
+//              the residue class r mod 2 (twiddle w_L^{2k}); lane bit 1 selects its lower or upper half.  Then lanes h and
+//              h ^ 1 combine G_0 and G_1 with twiddle w_L^{k + N a} = i^a w_L^k (a = h >> 1), lane bit 0 selecting X[m] or
+//              X[m + 2N]: lane h ends with block (h >> 1) + 2 (h & 1).
+template <int SPLIT>
+DEVI int split_block(int h)
+{
+    return SPLIT == 4 ? (h >> 1) + 2 * (h & 1) : h;
+}
+
 template <int L, int SPLIT, int K0 = 0>
 DEVI void combine_split(cplx *y, int h, const cplx *__restrict__ tw)
 {
@@ -151,6 +169,22 @@ DEVI void combine_split(cplx *y, int h, const cplx *__restrict__ tw)
         const cplx t = twiddle<L, K0>(o, tw);
         slot = h ? csub(e, t) : cadd(e, t);
         combine_split<L, SPLIT, K0 + 1>(y, h, tw);
+    } else if constexpr (SPLIT == 4 && K0 < N) {
+        constexpr int pos = fft_pos(N, K0);
+        cplx &slot = y[pos];
+        const bool up1 = (h & 2) != 0, up2 = (h & 1) != 0;
+        cplx mine = slot;
+        cplx other = {swap2(mine.x), swap2(mine.y)};
+        cplx e = up1 ? other : mine, o = up1 ? mine : other;
+        cplx t = twiddle<L, 2 * K0>(o, tw);
+        mine = up1 ? csub(e, t) : cadd(e, t);
+        other = {swap1(mine.x), swap1(mine.y)};
+        e = up2 ? other : mine;
+        o = up2 ? mine : other;
+        t = twiddle<L, K0>(o, tw);
+        if (up1) t = muli(t);
+        slot = up2 ? csub(e, t) : cadd(e, t);
+        combine_split<L, SPLIT, K0 + 1>(y, h, tw);
     }
 }
 
@@ -162,11 +196,12 @@ __global__ __launch_bounds__(WGS, OCC) void irfft2_fft_kernel(const float *__res
     static_assert(NB * K * SPLIT <= WGS, "a group's column transforms must fit the workgroup");
     extern __shared__ __attribute__((aligned(16))) char fft_smem[];
     cplx *ylds = (cplx *)fft_smem;   // [NB][K][CS]: column k of a lattice, rows split by parity: even rows first
-    const int t = threadIdx.x, h = SPLIT == 2 ? (t & 1) : 0, task = t / SPLIT;
+    const int t = threadIdx.x, h = SPLIT > 1 ? (t & (SPLIT - 1)) : 0, task = t / SPLIT;
+    const int hb = split_block<SPLIT>(h);   // the output block this lane holds after combine_split
     const int64_t ngroups = (B + NB - 1) / NB;
     // The (Re, Im) pairs of the next group are requested while the current one is transformed (float32, so the
     // prefetch costs 2N registers): with one or two wavefronts per SIMD nothing else would cover the HBM latency.
-    constexpr bool PF = N <= 32;
+    constexpr bool PF = N <= 16 || (N <= 32 && SPLIT == 1);   // (N = 32 on four lanes: the registers go to the transform)
     float2 pre[PF ? N : 1];
     const int lb1 = task / K, k1 = task - lb1 * K;
     auto fetch = [&](int64_t g) {
@@ -204,7 +239,7 @@ __global__ __launch_bounds__(WGS, OCC) void irfft2_fft_kernel(const float *__res
                 cplx *col = ylds + (lb * K + k) * CS;
                 static_for<0, N>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, slot = fft_pos(N, i);
-                    const int n = i + N * h;   // N is even (or SPLIT == 1): the parity of n is that of i
+                    const int n = i + N * hb;   // N is even (or SPLIT == 1): the parity of n is that of i
                     col[(i & 1) * HP + (n >> 1)] = y[slot];
                 });
             }
@@ -229,8 +264,8 @@ __global__ __launch_bounds__(WGS, OCC) void irfft2_fft_kernel(const float *__res
                 fft_inplace<N, L, 0, N>(y, tw.w);
                 combine_split<L, SPLIT>(y, h, tw.w);
                 const double norm = 1.0 / ((double)L * (double)L);
-                // this thread holds columns [N*h, N*h + N) of rows 2p (real parts) and 2p+1 (imaginary parts)
-                const int64_t row0 = (b * L + 2 * p) * L + N * h;
+                // this thread holds columns [N*hb, N*hb + N) of rows 2p (real parts) and 2p+1 (imaginary parts)
+                const int64_t row0 = (b * L + 2 * p) * L + N * hb;
                 if (real_out) {
                     static_for<0, N>([&](auto ic) {
                         constexpr int i = decltype(ic)::value, slot = fft_pos(N, i);
@@ -336,8 +371,11 @@ hipError_t launch_irfft2_fft(const float *spec, int64_t B, int L, int8_t *spins,
     case 24: return launch_fft<24, 1, 128>(spec, B, spins, real_out, s);
     case 32: return launch_fft<32, 1, 128>(spec, B, spins, real_out, s);
     case 40: return launch_fft<40, 1, 128>(spec, B, spins, real_out, s);
+    // 64: two lanes per transform (four measure 253 us against 215 us per 16 384 lattices: the second combine level costs more
+    // than the registers it frees); 128: four lanes (287 us against 631 us per 4 096 lattices: two lanes hold 64 float64
+    // complex each and spill)
     case 64: return launch_fft<64, 2, 256, 1>(spec, B, spins, real_out, s);
-    case 128: return launch_fft<128, 2, 256>(spec, B, spins, real_out, s);
+    case 128: return launch_fft<128, 4, 320, 1>(spec, B, spins, real_out, s);
     default: return hipErrorInvalidValue;
     }
 }

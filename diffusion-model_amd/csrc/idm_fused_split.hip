@@ -310,6 +310,156 @@ __global__ __launch_bounds__(512, 1) void fused_b_split_kernel(FusedArgs a)
     epilogue9_update(1, item_of(1, niter - 1));
 }
 
+// ---------------------------------------------------------------------------------------------
+// fused_M3 (conv6 + conv7 on the whole 16x16 map of the L = 32 pyramid) with the tile copies on wavefronts of their own.
+//
+// The four-wavefront kernel runs one workgroup per CU (its LDS tiles take 125 KB), i.e. one wavefront per SIMD, so its
+// stage-in, prefetch issue and copy-out - 4.5 k of a lattice's 32.8 k cycles - run while the matrix pipe idles.  Here
+// wavefronts 4-7 do those copies beside the MFMA wavefronts 0-3, which keep the convolutions and their epilogues:
+//
+//     MFMA wavefronts                         copy wavefronts
+//     conv6 (lattice i): loop, epilogue       copy-out of lattice i-1 (staging tile -> global); prefetch of lattice i+1
+//  B1 (input tiles free, mid tile complete)
+//     conv7 (lattice i): loop, epilogue       stage-in of lattice i+1 (registers -> input tiles)
+//  B2 (staging tile complete, input tiles staged)
+//
+// The staging tile therefore has room of its own (the four-wavefront kernel lays it over the input tiles): 79 + 46.7 +
+// 36.9 KB of tiles and 1 KB of constants just fit the 160 KB of a CU.  Partition, epilogue arithmetic and results are
+// those of fused2_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int NT1, int WD1, int NT2, int WD2>
+__global__ __launch_bounds__(512, 1) void fused_m3_split_kernel(FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int W = 16, H = 16, R = 16, CA = 128, CB = 64, C1 = 64, C2 = 64;
+    constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16, SM = C1 * 2 + 16, SO = C2 * 2 + 16;
+    constexpr int TILE_A = ((R / 2 + 2) * (W / 2 + 2) * SA + 15) & ~15, TILE_B = (R + 4) * (W + 2) * SB;
+    constexpr int IN = TILE_A + TILE_B, MID = (R + 2) * (W + 2) * SM, STAGE = R * W * SO;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool copier = wave >= 4;          // wave-uniform
+    const int rw = wave & 3, rtid = tid & 255;
+    const int h = lane >> 5;
+    const int nlat = (int)a.B;
+
+    char *tile_a = smem, *tile_b = smem + TILE_A, *mid = smem + IN, *stage = smem + IN + MID;
+    float *cst = (float *)(smem + IN + MID + STAGE);
+    const float *c_b1 = cst, *c_b2 = cst + C1;
+    for (int i = tid; i < C1; i += 512) cst[i] = a.b1[i];
+    for (int i = tid; i < C2; i += 512) cst[C1 + i] = a.b2[i];
+    // the mid tile's halo columns and its two padding rows (above and below the map) are never written afterwards
+    clear_halo<C1, 512>(mid, W, R + 2, 0, 1, tid);
+    clear_halo<C1, 512>(mid, W, 0, R + 1, R + 2, tid);
+    const int first = (int)blockIdx.x, step = (int)gridDim.x;
+    const LaneGeo geo = make_geo(W, lane & 31);
+
+    if (!copier) {
+        using Conv1 = ConvStage<CA, CB, true, C1, NT1, 1, WD1, false>;
+        using Conv2 = ConvStage<C1, 0, false, C2, NT2, 1, WD2, false>;
+        Conv1 cs1;
+        Conv2 cs2;
+        auto epi1 = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *, int mt, int r, int x, bool valid) {
+            if (!valid) return;
+            char *dst = mid + __mul24(__mul24(r, W + 2) + x + 1, SM) + (mt * 32 + 4 * h) * 2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                z = silu4(BIAS_IN_ACC ? z : z + kb[g]);
+                *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
+            }
+        };
+        auto epi2 = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *, int mt, int r, int x, bool valid) {
+            if (!valid) return;
+            char *dst = stage + __mul24(__mul24(r, W) + x, SO) + (mt * 32 + 4 * h) * 2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                z = silu4(BIAS_IN_ACC ? z : z + kb[g]);
+                *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
+            }
+        };
+        // (each stage's first weights are requested before the barrier that precedes it)
+        cs1.begin(tile_a, tile_b, c_b1, nullptr, geo, 1, R, (const bf16x8 *)a.w1, rw, lane, 0, 4);
+        __syncthreads();                       // constants, halo, the first lattice's tiles
+        for (int b = first; b < nlat; b += step) {
+            cs1.run(epi1);
+            cs2.begin(mid, nullptr, c_b2, nullptr, geo, 0, R, (const bf16x8 *)a.w2, rw, lane, 0, 4);
+            __syncthreads();                   // B1
+            cs2.run(epi2);
+            if (b + step < nlat) cs1.begin(tile_a, tile_b, c_b1, nullptr, geo, 1, R, (const bf16x8 *)a.w1, rw, lane, 0, 4);
+            __syncthreads();                   // B2
+        }
+        return;
+    }
+
+    TileRegs<CA, 5, 256> ra;
+    TileRegs<CB, 10, 256> rb;
+    auto pf_load = [&](int b) {
+        if (b >= nlat) return;
+        int t = rtid;
+        asm volatile("" : "+v"(t));
+        __builtin_assume(t >= 0 && t < 256);
+        ra.load((const __bf16 *)a.in_a + (size_t)b * (H / 2) * (W / 2) * CA, H / 2, W / 2, -1, (R >> 1) + 2, t);
+        rb.load((const __bf16 *)a.in_b + (size_t)b * H * W * CB, H, W, -2, R + 4, t);
+    };
+    auto stage_in = [&](int b) {
+        if (b >= nlat) return;
+        int t = rtid;
+        asm volatile("" : "+v"(t));
+        __builtin_assume(t >= 0 && t < 256);
+        ra.template store<true>(tile_a, W >> 1, (R >> 1) + 2, t);
+        rb.template store<true>(tile_b, W, R + 4, t);
+    };
+    auto copy_out = [&](int b) {
+        constexpr int CH = C2 / 8;
+        __bf16 *og = (__bf16 *)a.out + (size_t)b * H * W * C2;
+        for (int i = rtid; i < H * W * CH; i += 256) {
+            const int ch = i % CH, pos = i / CH;
+            *(bf16x8 *)(og + (size_t)pos * C2 + ch * 8) = *(const bf16x8 *)(stage + pos * SO + ch * 16);
+        }
+    };
+    pf_load(first);
+    stage_in(first);
+    __syncthreads();                           // constants, halo, the first lattice's tiles
+    for (int b = first; b < nlat; b += step) {
+        if (b != first) copy_out(b - step);
+        pf_load(b + step);
+        __syncthreads();                       // B1
+        stage_in(b + step);
+        __syncthreads();                       // B2
+    }
+    if (first < nlat) {
+        int last = first;
+        while (last + step < nlat) last += step;
+        copy_out(last);
+    }
+}
+
+hipError_t launch_m3_split(const FusedArgs &a, int64_t B, hipStream_t s)
+{
+    auto kernel = fused_m3_split_kernel<4, 2, 4, 3>;
+    constexpr int tile_a = ((16 / 2 + 2) * (16 / 2 + 2) * 272 + 15) & ~15, tile_b = 20 * 18 * 144, mid = 18 * 18 * 144,
+                  stage = 16 * 16 * 144;
+    constexpr int lds = tile_a + tile_b + mid + stage + (64 + 64) * 4;
+    static_assert(lds <= 160 * 1024, "the tiles must fit a CU");
+    static thread_local struct { bool configured = false; int cus = 0; } all_st[IDM_MAX_DEVICES];
+    const int slot = idm_device_slot();
+    if (slot < 0) return hipErrorInvalidDevice;
+    auto &st = all_st[slot];
+    if (!st.configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+        st.cus = prop.multiProcessorCount;
+        st.configured = true;
+    }
+    if (B >= ((int64_t)1 << 30)) return hipErrorInvalidValue;
+    const int64_t grid = std::min<int64_t>(B, (int64_t)st.cus);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
 // fused_b_split_kernel: one workgroup of eight wavefronts per CU, two lattices each.
 #ifndef IDM_CFG_BSPLIT
 #define IDM_CFG_BSPLIT 3, 2, 2, 3

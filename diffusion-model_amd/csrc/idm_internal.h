@@ -126,6 +126,8 @@ int fused_tall_rows(int kind, int H, int W);
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s);
 // fused_B for the L = 32 lattice, MFMA and non-MFMA work on separate wavefronts (idm_fused_split.hip)
 hipError_t launch_b_split(const FusedArgs &a, int64_t B, hipStream_t s);
+// fused_M3 for the L = 32 pyramid, tile copies on wavefronts of their own (idm_fused_split.hip)
+hipError_t launch_m3_split(const FusedArgs &a, int64_t B, hipStream_t s);
 
 // ---- single-convolution band/strip kernels (idm_strip.hip) ----
 enum StripKindId { SK_CONV1 = 0, SK_CONV2, SK_CONV3, SK_CONV4, SK_CONV5, SK_CONV6, SK_CONV7, SK_CONV8, SK_CONV9, SK_CONV9S, SK_CONV9H2, SK_COUNT };   // SK_CONV9: conv9 + head + update; SK_CONV9S: conv9 stored; SK_CONV9H2: conv9 + two-channel head

@@ -436,3 +436,28 @@ def test_split_schedule_of_fused_b_is_bit_identical(gpu_real, tmp_path):
         got = np.load(tmp_path / f"x{B}.npy")
         assert np.isfinite(got).all()
         assert np.array_equal(got, want.x_final.cpu().numpy()), B
+
+
+def test_fused_m3_with_copy_wavefronts_is_bit_identical(gpu_real, tmp_path):
+    """conv6 + conv7 of the L=32 bf16 sampler run by default with the tile copies on wavefronts of their own;
+    ISINGDIFF_M3_SPLIT=0 selects the four-wavefront kernel.  Same partition and arithmetic: same bits.  (The switch is
+    read once per process, hence the child process.)"""
+    import os, subprocess, sys
+    from isingdiff.sampler import sample, beta_schedule
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {os.path.join(root, 'diffusion-model_amd')!r})\n"
+        "from isingdiff import load_model, sample, beta_schedule\n"
+        f"m = load_model({os.path.join(root, 'weights', 'b_diffusion_model_2d_ising_realspace_unet.keras')!r}, device=0, precision='bf16')\n"
+        "for B in (1, 5, 777):\n"
+        "    r = sample(m, B, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision='bf16', keep_state=True)\n"
+        "    np.save(os.path.join(sys.argv[1], f'y{B}.npy'), r.x_final.cpu().numpy())\n")
+    env = dict(os.environ, ISINGDIFF_M3_SPLIT="0")
+    subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, env=env, timeout=240)
+    assert os.environ.get("ISINGDIFF_M3_SPLIT") != "0"
+    for B in (1, 5, 777):
+        want = sample(gpu_real, B, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision="bf16", keep_state=True)
+        got = np.load(tmp_path / f"y{B}.npy")
+        assert np.isfinite(got).all()
+        assert np.array_equal(got, want.x_final.cpu().numpy()), B

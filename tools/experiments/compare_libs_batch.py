@@ -1,5 +1,5 @@
 """Bitwise comparison of the bf16 sampler's final state between two builds of the library.
-    python tools/experiments/compare_libs_batch.py LIB_A LIB_B BATCH [T]
+    python tools/experiments/compare_libs_batch.py LIB_A LIB_B BATCH [T] [VAR=VALUE ...]   (the variables are set for LIB_A only)
 """
 import os, sys, subprocess, numpy as np
 ROOT = os.getcwd()
@@ -15,9 +15,12 @@ np.save(sys.argv[1], r.x_final.cpu().numpy())
 '''
 A, B_, batch = sys.argv[1], sys.argv[2], sys.argv[3]
 T = sys.argv[4] if len(sys.argv) > 4 else "3"
+extra = dict(v.split("=", 1) for v in sys.argv[5:])
 outs = []
 for name, lib in (("a", A), ("b", B_)):
     env = dict(os.environ, ISINGDIFF_LIB=os.path.join(ROOT, lib))
+    if name == "a":
+        env.update(extra)
     out = f"gpurun_out/cmp_{name}.npy"
     subprocess.run([sys.executable, "-c", code, out, batch, T], check=True, env=env, timeout=90)
     outs.append(np.load(out))

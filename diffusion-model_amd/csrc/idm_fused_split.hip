@@ -377,15 +377,27 @@ __global__ __launch_bounds__(512, 1) void fused_m3_split_kernel(FusedArgs a)
                 *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
             }
         };
-        // (each stage's first weights are requested before the barrier that precedes it)
-        cs1.begin(tile_a, tile_b, c_b1, nullptr, geo, 1, R, (const bf16x8 *)a.w1, rw, lane, 0, 4);
+        // Every lattice is the same work item: 2 cout slices x 8 two-row tiles per stage = 16 units, four vertically adjacent
+        // tiles of one slice per wavefront (slice rw / 2, tiles 4 (rw % 2) ...), as ConvStage::run() would deal them.  The
+        // stages are set up once; per lattice only the weight requests (before the barrier that precedes the stage) and
+        // the piece itself remain, so the operand addressing is loop-invariant.
+        static_assert(NT1 == 4 && NT2 == 4, "one four-tile piece per wavefront and stage");
+        const int sl = rw >> 1, j0 = (rw & 1) * 4;
+        cs1.begin(tile_a, tile_b, c_b1, nullptr, geo, 1, R, (const bf16x8 *)a.w1, rw, lane, 0, 4, true);
+        cs2.begin(mid, nullptr, c_b2, nullptr, geo, 0, R, (const bf16x8 *)a.w2, rw, lane, 0, 4, true);
+        cs1.set_weights((const bf16x8 *)a.w1, lane);
+        cs2.set_weights((const bf16x8 *)a.w2, lane);
+        cs1.set_slice(sl);
+        cs2.set_slice(sl);
+        auto nohook = [](int) {};
+        if (first < nlat) cs1.prologue();
         __syncthreads();                       // constants, halo, the first lattice's tiles
         for (int b = first; b < nlat; b += step) {
-            cs1.run(epi1);
-            cs2.begin(mid, nullptr, c_b2, nullptr, geo, 0, R, (const bf16x8 *)a.w2, rw, lane, 0, 4);
+            cs1.template piece<4>(j0, sl, 0, epi1, nohook);
+            cs2.prologue();
             __syncthreads();                   // B1
-            cs2.run(epi2);
-            if (b + step < nlat) cs1.begin(tile_a, tile_b, c_b1, nullptr, geo, 1, R, (const bf16x8 *)a.w1, rw, lane, 0, 4);
+            cs2.template piece<4>(j0, sl, 0, epi2, nohook);
+            if (b + step < nlat) cs1.prologue();
             __syncthreads();                   // B2
         }
         return;

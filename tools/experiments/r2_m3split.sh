@@ -1,9 +1,9 @@
 #!/bin/bash
-# fused_M3 with copy wavefronts (ISINGDIFF_M3_SPLIT=1) against the default schedule: bitwise comparison, then timing.
+# fused_M3 with copy wavefronts (default) against the four-wavefront kernel (ISINGDIFF_M3_SPLIT=0): bitwise comparison, then timing.
 set -o pipefail
 P=diffusion-model_amd/isingdiff/libisingdiff.so
 for b in 1 5 777 4096; do
-  timeout -k 10 200 python -u tools/experiments/compare_libs_batch.py $P $P $b 3 ISINGDIFF_M3_SPLIT=1 2>/dev/null || exit 1
+  timeout -k 10 200 python -u tools/experiments/compare_libs_batch.py $P $P $b 3 ISINGDIFF_M3_SPLIT=0 2>/dev/null || exit 1
 done
 for v in 0 1 0 1; do
   ISINGDIFF_M3_SPLIT=$v timeout -k 10 200 python -u bench.py --batch 8192 --T 50 --steps 1 --warmup 1 --no-cpu-baseline --fp32-lattices 0 > gpurun_out/bv.json 2> gpurun_out/bv.err || { tail -5 gpurun_out/bv.err; exit 1; }

@@ -702,14 +702,10 @@ hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
             return launch_one(st[8], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, IDM_CFG_M3, 16, 16, IDM_M3_WAVES>, a, B, s, IDM_M3_WAVES * 64);
         }
         default: {
-            // ISINGDIFF_B_SPLIT=1 (or a build with -DIDM_FUSED_B_SPLIT) selects the schedule of idm_fused_split.hip: the same
-            // results bit for bit, MFMA and non-MFMA work on separate wavefronts; slower than the two-workgroup schedule
-            // so far, kept for the comparison.
-#ifdef IDM_FUSED_B_SPLIT
-            static const bool split = true;
-#else
-            static const bool split = [] { const char *e = getenv("ISINGDIFF_B_SPLIT"); return e && e[0] == '1'; }();
-#endif
+            // the schedule of idm_fused_split.hip (one workgroup per CU, two lattices in flight, tile copies / noise / update on
+            // wavefronts of their own; the same results bit for bit, 3 % faster) unless ISINGDIFF_B_SPLIT=0 asks for the
+            // two independent four-wavefront workgroups per CU
+            static const bool split = [] { const char *e = getenv("ISINGDIFF_B_SPLIT"); return !(e && e[0] == '0'); }();
             if (split) return launch_b_split(a, B, s);
             return launch_one(st[9], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD, false, IDM_CFG_B, 32, IDM_B_WAVES == 8 ? 16 : 8, IDM_B_WAVES>, a, B, s, IDM_B_WAVES * 64);
         }

@@ -1,15 +1,18 @@
-// fused_B (conv8, conv9, head, reverse update) for the L = 32 lattice with the work split by kind over the eight
-// wavefronts of a workgroup.  This translation unit is compiled with -fno-slp-vectorize: its epilogues must stay on the
-// plain (unpacked) float32 ALU, because beside a wavefront that streams MFMAs packed float32 instructions wait for the
-// matrix pipe while plain ones do not (inline assembly is no alternative: the compiler does not see that it consumes a
+// Fused band kernels of the L = 32 pyramid with eight wavefronts per workgroup: four run the MFMA loops and their
+// epilogues, four (the second wavefront of each SIMD) do the tile copies, the noise draw and the state update beside
+// them.  A wavefront issues one instruction per ~8 cycles whatever its kind, so in the four-wavefront kernels that
+// bookkeeping runs while the matrix pipe idles; here it runs in the shadow of the other wavefront's MFMAs.
+// This translation unit is compiled with -fno-slp-vectorize: the copy wavefronts' arithmetic must stay on the plain
+// (unpacked) float32 ALU, because beside a wavefront that streams MFMAs packed float32 instructions wait for the matrix
+// pipe while plain ones do not (inline assembly is no alternative: the compiler does not see that it consumes a
 // transcendental's result and leaves out the wait state that needs).
 #include "idm_conv_stage.h"
 
 #include <algorithm>
 
 #ifdef IDM_TIMELINE
-// fused_b_split_kernel: [role][iteration][2 k] = arrival at barrier k + 1, [2 k + 1] = departure from it (wavefronts 0 and 4
-// of one workgroup).
+// fused_b_copy_kernel: [kind of wavefront][iteration][2 k] = arrival at barrier k + 1, [2 k + 1] = departure from it
+// (wavefronts 0 and 4 of one workgroup).
 __device__ long long g_tl3[2][64][16];
 extern "C" int idm_debug_timeline3(long long *host)
 {
@@ -22,293 +25,8 @@ extern "C" int idm_debug_timeline3(long long *host)
     } while (0)
 #define BAR(k) do { TLS(2 * (k) - 2); __syncthreads(); TLS(2 * (k) - 1); } while (0)
 #else
-#define TLS(i) do { } while (0)
 #define BAR(k) __syncthreads()
 #endif
-
-// ---------------------------------------------------------------------------------------------
-// fused_B for the L = 32 lattice with the work split by KIND over eight wavefronts (one workgroup per CU).
-//
-// A wavefront issues one instruction per ~8 cycles whatever its kind, and an MFMA holds the pipe for four such slots,
-// so the ~1 250 non-MFMA instructions a band costs a wavefront of the kernel above (epilogues, tile copies, noise
-// draw, update) cannot hide behind its own 144 MFMAs, and two independent workgroups per CU overlap them only by
-// chance.  Here wavefronts 0-3 (one per SIMD) run nothing but the two MFMA loops and hand their raw float32
-// accumulators over through LDS; wavefronts 4-7 (the second wavefront of each SIMD) do everything else.  Two lattices
-// ("streams" X and Y, each with its own input tiles and mid tile) are in flight so that both kinds always have work;
-// eight workgroup barriers per pair of bands keep them in step:
-//
-//     MFMA wavefronts                       other wavefronts
-//     conv8 loop (X)                        conv9 epilogue + head + state update of Y's previous band, carry rows
-//  B1 accumulators -> hand-over (X)         stage-in of Y's band (registers -> input tiles)
-//  B2 conv8 loop (Y)                        conv8 epilogue (X): hand-over -> bias/silu/pack -> mid tile; prefetch X's next band
-//  B3 accumulators -> hand-over (Y)
-//  B4 conv9 loop (X)                        conv8 epilogue (Y)
-//  B5 accumulators -> hand-over (X)
-//  B6 conv9 loop (Y)                        conv9 epilogue + head + update (X), carry rows
-//  B7 accumulators -> hand-over (Y)         stage-in of X's next band; prefetch Y's next band
-//  B8
-//
-// The hand-over buffer of a stream lies over its own input tiles (dead between a band's conv8 loop and the next
-// stage-in), which is why the accumulators are written only after the barrier that ends the loop (B1, B3, B5, B7: issued
-// from inside the convolution stage, between its last MFMA and its epilogue), and why stage-in rewrites the tiles' halo
-// columns every band.  Pixel stride of the hand-over is 144 bytes (32 float32 + 16): as for the activation tiles, the
-// 16-lane groups of a 16-byte access then fall on distinct banks.  The arithmetic of every epilogue, the Philox counters
-// and the update are those of fused2_kernel, so the results are bit-identical to it.
-// ---------------------------------------------------------------------------------------------
-template <int NT1, int WD1, int NT2, int WD2>
-__global__ __launch_bounds__(512, 1) void fused_b_split_kernel(FusedArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int W = 32, H = 32, R = 8, NBANDS = 4, CA = 64, CB = 32, C1 = 32, C2 = 32;
-    constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16, SM = C1 * 2 + 16, SH = 32 * 4 + 16;
-    constexpr int TILE_A = ((R / 2 + 2) * (W / 2 + 2) * SA + 15) & ~15, TILE_B = (R + 4) * (W + 2) * SB;
-    constexpr int IN = TILE_A + TILE_B, MID = (R + 2) * (W + 2) * SM, STREAM = IN + MID;
-    static_assert((R + 2) * W * SH <= IN, "the hand-over buffer must fit the input tiles it lies over");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool helper = wave >= 4;          // wave-uniform
-    const int rw = wave & 3, rtid = tid & 255;
-    const int h = lane >> 5, li = lane & 31;
-    const int nlat = (int)a.B;
-
-    float *cst = (float *)(smem + 2 * STREAM);
-    const float *c_b1 = cst, *c_b2 = cst + C1, *c_wh = cst + C1 + C2, *c_bh = cst + C1 + 2 * C2;
-    for (int i = tid; i < C1; i += 512) cst[i] = a.b1[i];
-    for (int i = tid; i < C2; i += 512) {
-        cst[C1 + i] = a.b2[i];
-        cst[C1 + C2 + i] = a.w_head[i];
-    }
-    if (tid == 0) cst[C1 + 2 * C2] = a.b_head[0];
-    auto tile_a = [&](int s) { return smem + s * STREAM; };
-    auto tile_b = [&](int s) { return smem + s * STREAM + TILE_A; };
-    auto mid = [&](int s) { return smem + s * STREAM + IN; };
-    auto handover = [&](int s) { return smem + s * STREAM; };
-    clear_halo<C1, 512>(mid(0), W, R + 2, 0, 0, tid);   // halo columns of the mid tiles: never written afterwards
-    clear_halo<C1, 512>(mid(1), W, R + 2, 0, 0, tid);
-
-    // Item n of stream s: band n % 4 of the workgroup's (n / 4)-th lattice of that stream.
-    struct Item { int b, y0; bool act; };
-    auto item_of = [&](int s, int n) {
-        Item it;
-        const int k = n >> 2;
-        it.b = (int)blockIdx.x + (2 * k + s) * (int)gridDim.x;
-        it.y0 = (n & 3) * R;
-        it.act = n >= 0 && it.b < nlat;
-        return it;
-    };
-    auto band_geo = [&](Item it, int &rlo, int &rhi) {
-        rlo = it.y0 == 0 ? 1 : 2;
-        rhi = min(R + 2, H - it.y0 + 1);
-    };
-    // lattices of stream X: blockIdx.x, blockIdx.x + 2 grid, ...; the loop runs until X has none left (Y ends no later)
-    const int per = 2 * (int)gridDim.x;
-    const int nx = (int)blockIdx.x < nlat ? (nlat - 1 - (int)blockIdx.x) / per + 1 : 0;
-    const int niter = nx * NBANDS;
-    const LaneGeo geo = make_geo(W, li);
-#ifdef IDM_BS_NOARM
-    constexpr bool ARM = false;
-#else
-    constexpr bool ARM = true;
-#endif
-
-    if (!helper) {
-        // ------------------------------ MFMA wavefronts ------------------------------
-#ifdef IDM_BS_PRIO
-        __builtin_amdgcn_s_setprio(IDM_BS_PRIO);
-#endif
-        using Conv1 = ConvStage<CA, CB, true, C1, NT1, 1, WD1, false>;
-        using Conv2 = ConvStage<C1, 0, false, C2, NT2, 1, WD2, false>;
-        Conv1 cs1;
-        Conv2 cs2;
-        auto begin8 = [&](int s, Item it) {
-            if (!it.act) return;
-            int rlo, rhi;
-            band_geo(it, rlo, rhi);
-            cs1.begin(tile_a(s), tile_b(s), c_b1, nullptr, geo, rlo, rhi - rlo, (const bf16x8 *)a.w1, rw, lane, 0, 4, ARM);
-        };
-        auto begin9 = [&](int s, Item it) {
-            if (!it.act) return;
-            cs2.begin(mid(s), nullptr, c_b2, nullptr, geo, 0, R, (const bf16x8 *)a.w2, rw, lane, 0, 4, ARM);
-        };
-        // runs the loop of one stage, meets the other wavefronts at the barrier that ends it, then writes the accumulators
-        int tls_n = 0;
-        (void)tls_n;
-        // (the first weights of a stage's next run are requested as soon as its loop ends: arm())
-        auto run_stage = [&](auto &cs, int s, bool act, int k) {
-            (void)k;
-            bool synced = false;
-            if (act) {
-                char *ho = handover(s);
-                cs.run(
-                    [&](const f32x16 &acc, const f32x4 *, const f32x4 *, int, int r, int x, bool valid) {
-                        if (!valid) return;
-                        char *dst = ho + (r * W + x) * SH + 16 * h;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            *(f32x4 *)(dst + 32 * q) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-                    },
-                    [&](int i) {
-                        if (i == 1 && !synced) {
-                            if (ARM) cs.arm();
-                            BAR(k);
-                            synced = true;
-                        }
-                    });
-            }
-            if (!synced) {
-                if (act && ARM) cs.arm();   // a wavefront without a piece in this band
-                BAR(k);
-            }
-        };
-        __syncthreads();                       // constants, halo columns, first stage-in
-        if (ARM) {
-            cs1.set_weights((const bf16x8 *)a.w1, lane);
-            cs2.set_weights((const bf16x8 *)a.w2, lane);
-            cs1.arm();
-            cs2.arm();
-        }
-        begin8(0, item_of(0, 0));
-        for (int n = 0; n < niter; ++n) {
-            const Item X = item_of(0, n), Y = item_of(1, n);
-            run_stage(cs1, 0, X.act, 1);       // B1 inside
-            begin8(1, Y);
-            BAR(2);
-            run_stage(cs1, 1, Y.act, 3);       // B3 inside
-            begin9(0, X);
-            BAR(4);
-            run_stage(cs2, 0, X.act, 5);       // B5 inside
-            begin9(1, Y);
-            BAR(6);
-            run_stage(cs2, 1, Y.act, 7);       // B7 inside
-            begin8(0, item_of(0, n + 1));
-            BAR(8);
-#ifdef IDM_TIMELINE
-            ++tls_n;
-#endif
-        }
-        return;
-    }
-
-    // ------------------------------ the other wavefronts ------------------------------
-    TileRegs<CA, 3, 256> ra;
-    TileRegs<CB, 6, 256> rb;
-    auto pf_load = [&](Item it) {
-        if (!it.act) return;
-        int t = rtid;
-        asm volatile("" : "+v"(t));
-        __builtin_assume(t >= 0 && t < 256);
-        ra.load((const __bf16 *)a.in_a + (size_t)it.b * (H / 2) * (W / 2) * CA, H / 2, W / 2, (it.y0 >> 1) - 1, (R >> 1) + 2, t);
-        rb.load((const __bf16 *)a.in_b + (size_t)it.b * H * W * CB, H, W, it.y0 - 2, R + 4, t);
-    };
-    auto stage_in = [&](int s, Item it) {
-        if (!it.act) return;
-        int t = rtid;
-        asm volatile("" : "+v"(t));
-        __builtin_assume(t >= 0 && t < 256);
-        ra.template store<true>(tile_a(s), W >> 1, (R >> 1) + 2, t);
-        rb.template store<true>(tile_b(s), W, R + 4, t);
-    };
-    // conv8's epilogue for the rows MFMA wavefront rw computed (the same even split of the band's rows)
-    auto epilogue8 = [&](int s, Item it) {
-        if (!it.act) return;
-        int rlo, rhi;
-        band_geo(it, rlo, rhi);
-        char *m = mid(s);
-        if (it.y0 == 0) clear_halo<C1, 256>(m, W, 0, 0, 1, rtid);              // padding row above the map
-        if (rhi < R + 2) clear_halo<C1, 256>(m, W, 0, rhi, R + 2, rtid);       // padding rows below it
-        const int tot = rhi - rlo, f = (rw * tot) >> 2, f1 = ((rw + 1) * tot) >> 2;
-        const char *ho = handover(s);
-        for (int r = rlo + f; r < rlo + f1; ++r) {
-            const char *src = ho + (r * W + li) * SH + 16 * h;
-            char *dst = m + (r * (W + 2) + li + 1) * SM + (4 * h) * 2;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 z = *(const f32x4 *)(src + 32 * q);
-                *(bf16x4 *)(dst + 16 * q) = pack4(silu1(z[0]), silu1(z[1]), silu1(z[2]), silu1(z[3]));
-            }
-        }
-    };
-    // conv9's epilogue, the 1x1 head and the state update for rows 2 rw and 2 rw + 1 of the band: after the reduction
-    // over the two half-waves every lane holds both rows' scores of its column, and lane half h updates row 2 rw + h.
-    auto epilogue9_update = [&](int s, Item it) {
-        if (!it.act) return;
-        const int row = 2 * rw + h;
-        const int e = (it.y0 + row) * W + li;
-        const int64_t off = (int64_t)it.b * (H * W) + e;
-        float xv = 0.f, zin = 0.f;
-        if (a.do_update) {
-            xv = a.x[off];
-            if (a.add_noise && a.noise) zin = a.noise[off];
-        }
-        f32x4 kw[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) kw[q] = *(const f32x4 *)(c_wh + 8 * q + 4 * h);
-        const char *ho = handover(s);
-        float sc2[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const char *src = ho + ((2 * rw + t) * W + li) * SH + 16 * h;
-            float p4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 z = *(const f32x4 *)(src + 32 * q);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) p4[i] += silu1(z[i]) * kw[q][i];
-            }
-            float part = (p4[0] + p4[1]) + (p4[2] + p4[3]);
-            part += __shfl_xor(part, 32, 64);
-            sc2[t] = part + c_bh[0];
-        }
-        const float sc = h ? sc2[1] : sc2[0];
-        if (a.score_out) a.score_out[off] = sc;
-        if (a.do_update) {
-            float z = zin;
-            if (a.add_noise && !a.noise) {
-                float z4[4];
-                uint32_t k0 = (uint32_t)a.ph.seed, k1 = (uint32_t)(a.ph.seed >> 32);
-                normal4(((uint64_t)k1 << 32) | k0, a.ph.first_global_index + it.b, (uint32_t)(e >> 2), a.ph.t, z4);
-                z = (e & 2) ? ((e & 1) ? z4[3] : z4[2]) : ((e & 1) ? z4[1] : z4[0]);
-            }
-            a.x[off] = reverse_update(a.c1, xv, a.beta, sc, z, a.sd, a.add_noise != 0);
-        }
-        // rows R, R+1 of the mid tile are rows 0, 1 of this lattice's next band
-        if (it.y0 + R < H) {
-            char *m = mid(s);
-            const int bytes = 2 * (W + 2) * SM;
-            const char *src = m + R * (W + 2) * SM;
-            for (int i = rtid * 16; i < bytes; i += 256 * 16) *(f32x4 *)(m + i) = *(const f32x4 *)(src + i);
-        }
-    };
-
-    int tls_n = 0;
-    (void)tls_n;
-    pf_load(item_of(0, 0));
-    stage_in(0, item_of(0, 0));
-    pf_load(item_of(1, 0));
-    __syncthreads();                           // constants, halo columns, first stage-in
-    for (int n = 0; n < niter; ++n) {
-        const Item X = item_of(0, n), Y = item_of(1, n);
-        epilogue9_update(1, item_of(1, n - 1));
-        BAR(1);
-        stage_in(1, Y);
-        BAR(2);
-        epilogue8(0, X);
-        pf_load(item_of(0, n + 1));
-        BAR(3);
-        BAR(4);
-        epilogue8(1, Y);
-        BAR(5);
-        BAR(6);
-        epilogue9_update(0, X);
-        BAR(7);
-        stage_in(0, item_of(0, n + 1));
-        pf_load(item_of(1, n + 1));
-        BAR(8);
-#ifdef IDM_TIMELINE
-        ++tls_n;
-#endif
-    }
-    epilogue9_update(1, item_of(1, niter - 1));
-}
 
 // ---------------------------------------------------------------------------------------------
 // fused_M3 (conv6 + conv7 on the whole 16x16 map of the L = 32 pyramid) with the tile copies on wavefronts of their own.
@@ -472,7 +190,257 @@ hipError_t launch_m3_split(const FusedArgs &a, int64_t B, hipStream_t s)
     return hipGetLastError();
 }
 
-// fused_b_split_kernel: one workgroup of eight wavefronts per CU, two lattices each.
+// ---------------------------------------------------------------------------------------------
+// fused_B (conv8, conv9, 1x1 head, reverse update) for the L = 32 lattice: one workgroup per CU, two lattices
+// ("streams" X and Y, each with its own input tiles, mid tile and score tile: 2 x 76 KB) in flight.
+//
+//     MFMA wavefronts 0-3                      copy wavefronts 4-7
+//     conv8 (X): loop, epilogue -> mid X       state update of Y's previous band (score tile Y, noise draw), carry rows Y
+//  B1
+//     conv8 (Y)                                stage-in of X's next band; prefetch of Y's next band
+//  B2
+//     conv9 (X): loop, epilogue, head -> score stage-in of Y's next band; prefetch of X's band after next
+//  B3
+//     conv9 (Y)                                state update of X's band, carry rows X
+//  B4
+//
+// Each stage's first weights are requested as soon as its previous run ends (arm()); the rows of a mid tile that lie
+// outside the map are cleared by the copy wavefronts while conv8 of that stream runs (its epilogue does not write them).
+// Partition, epilogue arithmetic, Philox counters and update are those of fused2_kernel: same results bit for bit.
+// ---------------------------------------------------------------------------------------------
+template <int NT1, int WD1, int NT2, int WD2>
+__global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int W = 32, H = 32, R = 8, CA = 64, CB = 32, C1 = 32, C2 = 32;
+    constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16, SM = C1 * 2 + 16;
+    constexpr int TILE_A = ((R / 2 + 2) * (W / 2 + 2) * SA + 15) & ~15, TILE_B = (R + 4) * (W + 2) * SB;
+    constexpr int IN = TILE_A + TILE_B, MID = (R + 2) * (W + 2) * SM, SCORE = R * W * 4, STREAM = IN + MID + SCORE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool copier = wave >= 4;          // wave-uniform
+    const int rw = wave & 3, rtid = tid & 255;
+    const int h = lane >> 5, li = lane & 31;
+    const int nlat = (int)a.B;
+
+    float *cst = (float *)(smem + 2 * STREAM);
+    const float *c_b1 = cst, *c_b2 = cst + C1, *c_wh = cst + C1 + C2, *c_bh = cst + C1 + 2 * C2;
+    for (int i = tid; i < C1; i += 512) cst[i] = a.b1[i];
+    for (int i = tid; i < C2; i += 512) {
+        cst[C1 + i] = a.b2[i];
+        cst[C1 + C2 + i] = a.w_head[i];
+    }
+    if (tid == 0) cst[C1 + 2 * C2] = a.b_head[0];
+    auto tile_a = [&](int s) { return smem + s * STREAM; };
+    auto tile_b = [&](int s) { return smem + s * STREAM + TILE_A; };
+    auto mid = [&](int s) { return smem + s * STREAM + IN; };
+    auto score = [&](int s) { return (float *)(smem + s * STREAM + IN + MID); };
+    for (int s = 0; s < 2; ++s) {
+        clear_halo<C1, 512>(mid(s), W, R + 2, 0, 0, tid);                  // halo columns: never written afterwards
+        clear_halo<CA, 512>(tile_a(s), W >> 1, (R >> 1) + 2, 0, 0, tid);
+        clear_halo<CB, 512>(tile_b(s), W, R + 4, 0, 0, tid);
+    }
+
+    // Item n of stream s: band n % 4 of the workgroup's (n / 4)-th lattice of that stream.
+    struct Item { int b, y0; bool act; };
+    auto item_of = [&](int s, int n) {
+        Item it;
+        const int k = n >> 2;
+        it.b = (int)blockIdx.x + (2 * k + s) * (int)gridDim.x;
+        it.y0 = (n & 3) * R;
+        it.act = n >= 0 && it.b < nlat;
+        return it;
+    };
+    auto band_geo = [&](Item it, int &rlo, int &rhi) {
+        rlo = it.y0 == 0 ? 1 : 2;
+        rhi = min(R + 2, H - it.y0 + 1);
+    };
+    const int per = 2 * (int)gridDim.x;
+    const int nx = (int)blockIdx.x < nlat ? (nlat - 1 - (int)blockIdx.x) / per + 1 : 0;
+    const int niter = nx * 4;   // stream Y ends no later than stream X
+    const LaneGeo geo = make_geo(W, li);
+
+    if (!copier) {
+        using Conv1 = ConvStage<CA, CB, true, C1, NT1, 1, WD1, false>;
+        using Conv2 = ConvStage<C1, 0, false, C2, NT2, 1, WD2, true>;
+        Conv1 cs1;
+        Conv2 cs2;
+        cs1.set_weights((const bf16x8 *)a.w1, lane);
+        cs2.set_weights((const bf16x8 *)a.w2, lane);
+        auto conv8 = [&](int s, Item it) {
+            if (it.act) {
+                int rlo, rhi;
+                band_geo(it, rlo, rhi);
+                char *m = mid(s);
+                cs1.begin(tile_a(s), tile_b(s), c_b1, nullptr, geo, rlo, rhi - rlo, (const bf16x8 *)a.w1, rw, lane, 0, 4, true);
+                cs1.run([&](const f32x16 &acc, const f32x4 *kb, const f32x4 *, int mt, int r, int x, bool valid) {
+                    if (!valid) return;
+                    char *dst = m + __mul24(__mul24(r, W + 2) + x + 1, SM) + (mt * 32 + 4 * h) * 2;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                        z = silu4(BIAS_IN_ACC ? z : z + kb[g]);
+                        *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
+                    }
+                });
+            }
+            cs1.arm();
+        };
+        // conv9 is the same work item in every band (rows 2 rw, 2 rw + 1 of a full eight-row band): set up once per stream
+        // (the streams differ in their tiles only), so its operand addressing leaves the band loop
+        static_assert(NT2 == 2, "one two-tile piece per wavefront");
+        Conv2 cs2b;
+        cs2b.set_weights((const bf16x8 *)a.w2, lane);
+        cs2.begin(mid(0), nullptr, c_b2, c_wh, geo, 0, R, (const bf16x8 *)a.w2, rw, lane, 0, 4, true);
+        cs2b.begin(mid(1), nullptr, c_b2, c_wh, geo, 0, R, (const bf16x8 *)a.w2, rw, lane, 0, 4, true);
+        cs2.set_slice(0);
+        cs2b.set_slice(0);
+        auto nohook = [](int) {};
+        auto conv9 = [&](auto &cs, int s, Item it) {
+            if (it.act) {
+                float *sc = score(s);
+                cs.template piece<2>(2 * rw, 0, 0, [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *kw, int, int r, int x, bool valid) {
+                    f32x4 p4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                        p4 += silu4(BIAS_IN_ACC ? z : z + kb[g]) * kw[g];
+                    }
+                    float part = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+                    part += __shfl_xor(part, 32, 64);
+                    if (valid && h == 0) sc[r * W + x] = part + c_bh[0];
+                }, nohook);
+            }
+        };
+        cs1.arm();
+        cs2.prologue();
+        __syncthreads();                       // constants, halo columns, the first bands' tiles
+        for (int n = 0; n < niter; ++n) {
+#ifdef IDM_TIMELINE
+            const int tls_n = n;
+#endif
+            const Item X = item_of(0, n), Y = item_of(1, n);
+            conv8(0, X);
+            BAR(1);
+            conv8(1, Y);
+            BAR(2);
+            conv9(cs2, 0, X);
+            cs2b.prologue();                   // (the two objects' weight rings: each is refilled while the other runs)
+            BAR(3);
+            conv9(cs2b, 1, Y);
+            cs2.prologue();
+            BAR(4);
+        }
+        return;
+    }
+
+    // ------------------------------ copy wavefronts ------------------------------
+    // one set of prefetch registers per stream: a stream's next band is requested two slots before it is staged, and
+    // the requests are issued during the conv9 slots (beside conv8 they slow its weight stream)
+    TileRegs<CA, 3, 256> ra[2];
+    TileRegs<CB, 6, 256> rb[2];
+    auto pf_load = [&](auto &qa, auto &qb, Item it) {
+        if (!it.act) return;
+        int t = rtid;
+        asm volatile("" : "+v"(t));
+        __builtin_assume(t >= 0 && t < 256);
+        qa.load((const __bf16 *)a.in_a + (size_t)it.b * (H / 2) * (W / 2) * CA, H / 2, W / 2, (it.y0 >> 1) - 1, (R >> 1) + 2, t);
+        qb.load((const __bf16 *)a.in_b + (size_t)it.b * H * W * CB, H, W, it.y0 - 2, R + 4, t);
+    };
+    auto stage_in = [&](auto &qa, auto &qb, int s, Item it) {
+        if (!it.act) return;
+        int t = rtid;
+        asm volatile("" : "+v"(t));
+        __builtin_assume(t >= 0 && t < 256);
+        qa.template store<false>(tile_a(s), W >> 1, (R >> 1) + 2, t);
+        qb.template store<false>(tile_b(s), W, R + 4, t);
+    };
+    // rows of the mid tile outside the map are conv9's zero padding
+    auto clear_pad_rows = [&](int s, Item it) {
+        if (!it.act) return;
+        int rlo, rhi;
+        band_geo(it, rlo, rhi);
+        if (it.y0 == 0) clear_halo<C1, 256>(mid(s), W, 0, 0, 1, rtid);
+        if (rhi < R + 2) clear_halo<C1, 256>(mid(s), W, 0, rhi, R + 2, rtid);
+    };
+    // The 64 float4 quads of a band (one Philox counter each) are one wavefront's worth of lanes: the copy wavefronts take
+    // the bands in turn, so that the noise draw - mostly quarter-rate integer multiplies, which hold the vector ALU that the
+    // MFMA wavefront of the SIMD issues through - costs each SIMD one band in four.
+    f32x4 xq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, zq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    auto my_turn = [&](int s, int n) { return ((n + 2 * s) & 3) == rw; };
+    auto quad_of = [&](Item it, int &qs, int64_t &off) {
+        const int qr = lane >> 3, qx = lane & 7;
+        qs = qr * W + qx * 4;
+        off = (int64_t)it.b * (H * W) + (it.y0 + qr) * W + qx * 4;
+    };
+    auto x_fetch = [&](int s, Item it, int n) {
+        if (!it.act || !a.do_update || !my_turn(s, n)) return;
+        int qs;
+        int64_t off;
+        quad_of(it, qs, off);
+        xq[s] = *(const f32x4 *)(a.x + off);
+        if (a.add_noise && a.noise) zq[s] = *(const f32x4 *)(a.noise + off);
+    };
+    auto update = [&](int s, Item it, int n) {
+        if (!it.act) return;
+        if (my_turn(s, n)) {
+            int qs;
+            int64_t off;
+            quad_of(it, qs, off);
+            const f32x4 sc = *(const f32x4 *)(score(s) + qs);
+            if (a.score_out) *(f32x4 *)(a.score_out + off) = sc;
+            if (a.do_update) {
+                float z[4] = {zq[s][0], zq[s][1], zq[s][2], zq[s][3]};
+                if (a.add_noise && !a.noise) {
+                    uint32_t k0 = (uint32_t)a.ph.seed, k1 = (uint32_t)(a.ph.seed >> 32);
+                    normal4(((uint64_t)k1 << 32) | k0, a.ph.first_global_index + it.b, (uint32_t)((off - (int64_t)it.b * (H * W)) >> 2),
+                            a.ph.t, z);
+                }
+                f32x4 xv = xq[s];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xv[j] = reverse_update(a.c1, xv[j], a.beta, sc[j], z[j], a.sd, a.add_noise != 0);
+                *(f32x4 *)(a.x + off) = xv;
+            }
+        }
+        // rows R, R+1 of the mid tile are rows 0, 1 of this lattice's next band
+        if (it.y0 + R < H) {
+            char *m = mid(s);
+            const int bytes = 2 * (W + 2) * SM;
+            const char *src = m + R * (W + 2) * SM;
+            for (int i = rtid * 16; i < bytes; i += 256 * 16) *(f32x4 *)(m + i) = *(const f32x4 *)(src + i);
+        }
+    };
+
+    pf_load(ra[0], rb[0], item_of(0, 0));
+    pf_load(ra[1], rb[1], item_of(1, 0));
+    stage_in(ra[0], rb[0], 0, item_of(0, 0));
+    stage_in(ra[1], rb[1], 1, item_of(1, 0));
+    pf_load(ra[0], rb[0], item_of(0, 1));
+    pf_load(ra[1], rb[1], item_of(1, 1));
+    __syncthreads();                           // constants, halo columns, the first bands' tiles
+    for (int n = 0; n < niter; ++n) {
+#ifdef IDM_TIMELINE
+        const int tls_n = n;
+#endif
+        const Item X = item_of(0, n), Y = item_of(1, n);
+        update(1, item_of(1, n - 1), n - 1);
+        clear_pad_rows(0, X);
+        BAR(1);
+        stage_in(ra[0], rb[0], 0, item_of(0, n + 1));
+        clear_pad_rows(1, Y);
+        x_fetch(0, X, n);
+        BAR(2);
+        stage_in(ra[1], rb[1], 1, item_of(1, n + 1));
+        pf_load(ra[0], rb[0], item_of(0, n + 2));
+        BAR(3);
+        update(0, X, n);
+        x_fetch(1, Y, n);
+        pf_load(ra[1], rb[1], item_of(1, n + 2));
+        BAR(4);
+    }
+    update(1, item_of(1, niter - 1), niter - 1);
+}
+
+// fused_b_copy_kernel: NT1, WD1, NT2, WD2
 #ifndef IDM_CFG_BSPLIT
 #define IDM_CFG_BSPLIT 3, 2, 2, 3
 #endif
@@ -482,9 +450,10 @@ hipError_t launch_b_split(const FusedArgs &a, int64_t B, hipStream_t s)
     const int slot = idm_device_slot();
     if (slot < 0) return hipErrorInvalidDevice;
     auto &st = all_st[slot];
-    auto kernel = fused_b_split_kernel<IDM_CFG_BSPLIT>;
-    constexpr int tile_a = ((8 / 2 + 2) * (32 / 2 + 2) * 144 + 15) & ~15, tile_b = 12 * 34 * 80, mid = 10 * 34 * 80;
-    constexpr int lds = 2 * (tile_a + tile_b + mid) + (32 + 3 * 32 + 4) * 4;
+    auto kernel = fused_b_copy_kernel<IDM_CFG_BSPLIT>;
+    constexpr int tile_a = ((8 / 2 + 2) * (32 / 2 + 2) * 144 + 15) & ~15, tile_b = 12 * 34 * 80, mid = 10 * 34 * 80, score = 8 * 32 * 4;
+    constexpr int lds = 2 * (tile_a + tile_b + mid + score) + (32 + 2 * 32 + 4) * 4;
+    static_assert(lds <= 160 * 1024, "the tiles must fit a CU");
     if (!st.configured) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -499,4 +468,3 @@ hipError_t launch_b_split(const FusedArgs &a, int64_t B, hipStream_t s)
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(512), lds, s, a);
     return hipGetLastError();
 }
-

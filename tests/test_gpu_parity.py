@@ -412,11 +412,12 @@ def test_bf16_update_is_the_canonical_expression_of_its_score(gpu_real, L):
         assert np.array_equal(new.view(np.uint32), want.view(np.uint32))
 
 
-def test_split_schedule_of_fused_b_is_bit_identical(gpu_real, tmp_path):
-    """ISINGDIFF_B_SPLIT=1 runs conv8 / conv9 / head / update of the L=32 bf16 sampler with MFMA and non-MFMA work on
-    separate wavefronts (two lattices in flight per workgroup); the arithmetic is the fused kernel's, so the final state
-    must be the same bit for bit.  Odd and small batches cover workgroups whose second lattice stream runs dry.  (The
-    switch is read once per process, hence the child process.)"""
+def test_copy_wavefront_kernels_are_bit_identical_to_the_four_wavefront_ones(gpu_real, tmp_path):
+    """At L=32 the bf16 sampler runs conv6 + conv7 and conv8 + conv9 + head + update in workgroups of eight wavefronts
+    (four for the MFMA loops and epilogues, four for tile copies, noise draw and update; csrc/idm_fused_split.hip).
+    ISINGDIFF_M3_SPLIT=0 / ISINGDIFF_B_SPLIT=0 select the four-wavefront kernels.  Same partition, arithmetic and Philox
+    counters: the final state must be the same bit for bit.  Odd and small batches cover workgroups whose second lattice
+    stream runs dry.  (The switches are read once per process, hence the child processes.)"""
     import os, subprocess, sys
     from isingdiff.sampler import sample, beta_schedule
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -427,37 +428,14 @@ def test_split_schedule_of_fused_b_is_bit_identical(gpu_real, tmp_path):
         f"m = load_model({os.path.join(root, 'weights', 'b_diffusion_model_2d_ising_realspace_unet.keras')!r}, device=0, precision='bf16')\n"
         "for B in (1, 5, 777):\n"
         "    r = sample(m, B, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision='bf16', keep_state=True)\n"
-        "    np.save(os.path.join(sys.argv[1], f'x{B}.npy'), r.x_final.cpu().numpy())\n")
-    env = dict(os.environ, ISINGDIFF_B_SPLIT="1")
-    subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, env=env, timeout=240)
-    assert os.environ.get("ISINGDIFF_B_SPLIT") != "1"
+        "    np.save(os.path.join(sys.argv[1], f'{sys.argv[2]}{B}.npy'), r.x_final.cpu().numpy())\n")
+    assert "ISINGDIFF_M3_SPLIT" not in os.environ and "ISINGDIFF_B_SPLIT" not in os.environ
+    for tag, env in (("m", {"ISINGDIFF_M3_SPLIT": "0"}), ("b", {"ISINGDIFF_B_SPLIT": "0"})):
+        subprocess.run([sys.executable, "-c", code, str(tmp_path), tag], check=True, env=dict(os.environ, **env), timeout=240)
     for B in (1, 5, 777):
         want = sample(gpu_real, B, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision="bf16", keep_state=True)
-        got = np.load(tmp_path / f"x{B}.npy")
-        assert np.isfinite(got).all()
-        assert np.array_equal(got, want.x_final.cpu().numpy()), B
-
-
-def test_fused_m3_with_copy_wavefronts_is_bit_identical(gpu_real, tmp_path):
-    """conv6 + conv7 of the L=32 bf16 sampler run by default with the tile copies on wavefronts of their own;
-    ISINGDIFF_M3_SPLIT=0 selects the four-wavefront kernel.  Same partition and arithmetic: same bits.  (The switch is
-    read once per process, hence the child process.)"""
-    import os, subprocess, sys
-    from isingdiff.sampler import sample, beta_schedule
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import os, sys, numpy as np, torch\n"
-        f"sys.path.insert(0, {os.path.join(root, 'diffusion-model_amd')!r})\n"
-        "from isingdiff import load_model, sample, beta_schedule\n"
-        f"m = load_model({os.path.join(root, 'weights', 'b_diffusion_model_2d_ising_realspace_unet.keras')!r}, device=0, precision='bf16')\n"
-        "for B in (1, 5, 777):\n"
-        "    r = sample(m, B, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision='bf16', keep_state=True)\n"
-        "    np.save(os.path.join(sys.argv[1], f'y{B}.npy'), r.x_final.cpu().numpy())\n")
-    env = dict(os.environ, ISINGDIFF_M3_SPLIT="0")
-    subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, env=env, timeout=240)
-    assert os.environ.get("ISINGDIFF_M3_SPLIT") != "0"
-    for B in (1, 5, 777):
-        want = sample(gpu_real, B, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision="bf16", keep_state=True)
-        got = np.load(tmp_path / f"y{B}.npy")
-        assert np.isfinite(got).all()
-        assert np.array_equal(got, want.x_final.cpu().numpy()), B
+        want = want.x_final.cpu().numpy()
+        for tag in ("m", "b"):
+            got = np.load(tmp_path / f"{tag}{B}.npy")
+            assert np.isfinite(got).all()
+            assert np.array_equal(got, want), (tag, B)

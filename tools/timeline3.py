@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Slot times of the split-role fused_B kernel (library built with -DIDM_TIMELINE -DIDM_FUSED_B_SPLIT)."""
+"""Slot times of the copy-wavefront fused_B kernel (library built with -DIDM_TIMELINE, run with ISINGDIFF_B_SPLIT=1)."""
 import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,13 +20,13 @@ n = int((t[0, :, 0] > 0).sum())
 sl = slice(4, n - 1)
 per = np.diff(t[0, 4:n, 0]).mean()
 print(f"iterations recorded {n}; period per pair of bands {per:.0f} cycles")
-names = ["conv8 X | epi9+update Y'", "hand-over X | stage-in Y", "conv8 Y | epi8 X + prefetch", "hand-over Y | -", "conv9 X | epi8 Y",
-         "hand-over X | -", "conv9 Y | epi9+update X", "hand-over Y | stage-in X' + prefetch"]
+names = ["conv8 X | update Y', carry", "conv8 Y | stage-in X', prefetch Y'", "conv9 X | stage-in Y', prefetch X''", "conv9 Y | update X, carry"]
+NS = len(names)
 for role, rn in ((0, "MFMA wavefront 0"), (1, "other wavefront 4")):
     a = t[role, sl].astype(np.float64)
-    prev_depart = np.concatenate([t[role, 3:n - 2, 15:16].astype(np.float64), a[:, 1::2][:, :7]], axis=1)   # departure from the previous barrier
-    work = a[:, 0::2] - prev_depart
-    wait = a[:, 1::2] - a[:, 0::2]
+    prev_depart = np.concatenate([t[role, 3:n - 2, 2 * NS - 1:2 * NS].astype(np.float64), a[:, 1:2 * NS:2][:, :NS - 1]], axis=1)   # departure from the previous barrier
+    work = a[:, 0:2 * NS:2] - prev_depart
+    wait = a[:, 1:2 * NS:2] - a[:, 0:2 * NS:2]
     print(rn)
-    for k in range(8):
+    for k in range(NS):
         print(f"   slot {k + 1} ({names[k]}): work {work[:, k].mean():7.0f}   wait at barrier {wait[:, k].mean():7.0f}")

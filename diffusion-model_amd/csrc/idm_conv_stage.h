@@ -162,7 +162,9 @@ DEVI LaneGeo make_geo(int W, int li)
 // Epilogue constants: c0 (bias) and, when HAS_C1, a second per-cout array c1 live in LDS as float32.  The 16 bias values a
 // lane needs per cout tile are read before the first superstep and start the accumulators; the 16 of c1 are read during the
 // last superstep.  Both are handed to epi(), whose accumulator already includes the bias.
-template <int CA, int CB, bool UP, int COUT, int NT, int MS, int WD, bool HAS_C1>
+// EXACT: every tile of a piece lies inside the stage's rows (32-pixel-wide maps: one row per tile, pieces never longer than
+// the rows left), so the fragment rows need no clamping and are one base address plus compile-time steps.
+template <int CA, int CB, bool UP, int COUT, int NT, int MS, int WD, bool HAS_C1, bool EXACT = false>
 struct ConvStage {
     static constexpr int MTOT = COUT / 32, NSL = MTOT / MS;
     static constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16;
@@ -293,18 +295,21 @@ struct ConvStage {
             const int first = __mul24(t >> 1, PU), last = __mul24((rmax + up_rb) >> 1, PU);
             const int odd = (t & 1) ? PU : 0;   // half-resolution row of fragment i: (t >> 1) + ((t & 1) + i >> 1)
 #pragma unroll
-            for (int i = 0; i < N + 2; ++i) a_up[i] = min(first + (i >> 1) * PU + ((i & 1) ? odd : 0), last);
+            for (int i = 0; i < N + 2; ++i) {
+                const int v = first + (i >> 1) * PU + ((i & 1) ? odd : 0);
+                a_up[i] = EXACT ? v : min(v, last);
+            }
         } else {
             const int PA = Wp2 * SA, col = ca * SA + h * 16;
             const int first = __mul24(rbase, PA) + col, last = __mul24(rmax, PA) + col;
 #pragma unroll
-            for (int i = 0; i < N + 2; ++i) a_pl[i] = min(first + i * PA, last);
+            for (int i = 0; i < N + 2; ++i) a_pl[i] = EXACT ? first + i * PA : min(first + i * PA, last);
         }
         if constexpr (CB > 0) {
             const int PB = Wp2 * SB, col = ca * SB + h * 16;
             const int first = __mul24(rbase, PB) + col, last = __mul24(rmax, PB) + col;
 #pragma unroll
-            for (int i = 0; i < N + 2; ++i) a_b[i] = min(first + i * PB, last);
+            for (int i = 0; i < N + 2; ++i) a_b[i] = EXACT ? first + i * PB : min(first + i * PB, last);
         }
         if constexpr (UP) {
 #pragma unroll

@@ -260,8 +260,8 @@ __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
     const LaneGeo geo = make_geo(W, li);
 
     if (!copier) {
-        using Conv1 = ConvStage<CA, CB, true, C1, NT1, 1, WD1, false>;
-        using Conv2 = ConvStage<C1, 0, false, C2, NT2, 1, WD2, true>;
+        using Conv1 = ConvStage<CA, CB, true, C1, NT1, 1, WD1, false, true>;
+        using Conv2 = ConvStage<C1, 0, false, C2, NT2, 1, WD2, true, true>;
         Conv1 cs1;
         Conv2 cs2;
         cs1.set_weights((const bf16x8 *)a.w1, lane);

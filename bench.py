@@ -35,7 +35,7 @@ PEAK_HBM_GBS = 8000.0
 # x out), from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes kept in profiles/r02/pmc_hbm.txt
 # (FETCH_SIZE doubled: gfx950 counts 16-byte-per-lane streaming reads at half their bytes).
 # Counters cannot be read inside this script; tools/measure_round.sh collects them with the same library.
-PMC_HBM_BYTES_PER_LATTICE = {"fused_B(conv8,9,head,step)": 105.9 * 1024}
+PMC_HBM_BYTES_PER_LATTICE = {"fused_B(conv8,9,head,step)": 104.1 * 1024}
 
 
 def cpu_baseline(spec, L, T, betas, budget_s=20.0):

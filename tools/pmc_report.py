@@ -19,7 +19,8 @@ for path in sys.argv[1:]:
     with open(path) as f:
         for r in csv.DictReader(f):
             k = r["Kernel_Name"]
-            k = k[k.find("fused2_kernel"):][:70] if "fused2_kernel" in k else k[:70]
+            k = k[5:] if k.startswith("void ") else k
+            k = k[:70]
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             key = (path, k, r["Dispatch_Id"])
             if key not in seen and r["Counter_Name"].startswith("GRBM_GUI_ACTIVE"):
@@ -28,7 +29,7 @@ for path in sys.argv[1:]:
                 cnt[(path, k)] += 1
 for k, c in acc.items():
     paths = [p for (p, kk) in dur if kk == k]
-    if not paths or "fused2" not in k and "strip" not in k and "irfft" not in k and "conv" not in k:
+    if not paths or not any(w in k for w in ("fused", "strip", "irfft", "conv")):
         continue
     p0 = paths[0]
     d, n = dur[(p0, k)], cnt[(p0, k)]

@@ -371,10 +371,10 @@ hipError_t launch_irfft2_fft(const float *spec, int64_t B, int L, int8_t *spins,
     case 24: return launch_fft<24, 1, 128>(spec, B, spins, real_out, s);
     case 32: return launch_fft<32, 1, 128>(spec, B, spins, real_out, s);
     case 40: return launch_fft<40, 1, 128>(spec, B, spins, real_out, s);
-    // 64: two lanes per transform (four measure 253 us against 215 us per 16 384 lattices: the second combine level costs more
-    // than the registers it frees); 128: four lanes (287 us against 631 us per 4 096 lattices: two lanes hold 64 float64
+    // 64: two lanes per transform, four lattices per workgroup (193 us per 16 384 lattices; three lattices in 256 threads:
+    // 218 us; four lanes per transform: 229 - 253 us, the second combine level costs more than the registers it frees); 128: four lanes (287 us against 631 us per 4 096 lattices: two lanes hold 64 float64
     // complex each and spill)
-    case 64: return launch_fft<64, 2, 256, 1>(spec, B, spins, real_out, s);
+    case 64: return launch_fft<64, 2, 320, 1>(spec, B, spins, real_out, s);
     case 128: return launch_fft<128, 4, 320, 1>(spec, B, spins, real_out, s);
     default: return hipErrorInvalidValue;
     }

@@ -1,12 +1,13 @@
 #!/bin/bash
 # SQ / GRBM counter passes for the fused band kernels on a short slice of the bench (16 384 lattices, 20 steps):
 # MFMA-busy, vector-ALU, wait and LDS-conflict shares per kernel, and the clock each kernel ran at.
+# PMC_CMD replaces the profiled python command (e.g. "tools/bench_fft.py 32 64"), PMC_OUT the output directory.
 # Each pass is its own rocprofv3 run (at most 8 SQ counters per pass).  Outputs under gpurun_out/pmc/; the summary
 # printed by tools/pmc_report.py is what gets copied to profiles/.
 set -o pipefail
-out=gpurun_out/pmc; mkdir -p $out
+out=${PMC_OUT:-gpurun_out/pmc}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-args="bench.py --batch ${PMC_BATCH:-16384} --L ${PMC_L:-32} --T 20 --no-cpu-baseline --no-profile"
+args="${PMC_CMD:-bench.py --batch ${PMC_BATCH:-16384} --L ${PMC_L:-32} --T 20 --no-cpu-baseline --no-profile --fp32-lattices 0}"
 pass() { name=$1; shift
   timeout -s KILL 150 rocprofv3 --pmc "$@" -d $out/$name -o s --output-format csv -- python3 $args > $out/$name.log 2>&1 || { tail -5 $out/$name.log; exit 1; }
   echo "pass $name done"; }

@@ -277,11 +277,15 @@ struct ConvStage {
     }
 
     struct NoHook { DEVI void operator()(int) const {} };
+    struct NoInter { template <class S> DEVI void operator()(S) const {} };
 
     // hook(0): operands addressed, before the first fragment read; hook(1): after the last MFMA; hook(2): after the
     // epilogue; hook(3 + i): after the epilogue of the piece's i-th tile, i < 3 (timing builds; a no-op otherwise).
-    template <int N, class Epi, class Hook>
-    DEVI void piece(int j, int sl, int cb, Epi &&epi, Hook &&hook)
+    // inter(integral_constant<int, st>) is called once in every superstep, in the same scheduling region as that
+    // superstep's MFMAs: work that does not depend on this piece (another piece's epilogue) issues in their shadow.
+    // An epi that takes a leading integral_constant<int, tile> is told which tile of the piece it is handed.
+    template <int N, class Epi, class Hook, class Inter = NoInter>
+    DEVI void piece(int j, int sl, int cb, Epi &&epi, Hook &&hook, Inter &&inter = Inter{})
     {
         const int W = g.W, Wp2 = W + 2, Wh2 = (W >> 1) + 2;
         const int cc = cb * 32 + g.col;
@@ -385,6 +389,7 @@ struct ConvStage {
                         if constexpr (HAS_C1) k1[m][q] = *(const f32x4 *)(c1 + co);
                     }
             }
+            inter(S);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -427,14 +432,17 @@ struct ConvStage {
         }
         hook(7);
 #endif
-#pragma unroll
-        for (int m = 0; m < MS; ++m)
-#pragma unroll
-            for (int n = 0; n < N; ++n)
-            {
-                epi(acc[m][n], k0[m], k1[m], sl * MS + m, rbase + n, cc, g.ok && cc < W && j + n + g.slot * Rh < nrows);
-                if (m * N + n < 3) hook(3 + m * N + n);
-            }
+        constexpr bool INDEXED = std::is_invocable_v<Epi &, std::integral_constant<int, 0>, const f32x16 &, const f32x4 *,
+                                                     const f32x4 *, int, int, int, bool>;
+        static_for<0, MS * N>([&](auto T) {
+            constexpr int m = decltype(T)::value / N, n = decltype(T)::value % N;
+            const bool valid = g.ok && cc < W && j + n + g.slot * Rh < nrows;
+            if constexpr (INDEXED)
+                epi(T, acc[m][n], k0[m], k1[m], sl * MS + m, rbase + n, cc, valid);
+            else
+                epi(acc[m][n], k0[m], k1[m], sl * MS + m, rbase + n, cc, valid);
+            if (m * N + n < 3) hook(3 + m * N + n);
+        });
 #ifdef IDM_EXP_PRIO_EPI
         __builtin_amdgcn_s_setprio(0);
 #endif

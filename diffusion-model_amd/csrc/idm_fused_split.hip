@@ -9,6 +9,7 @@
 #include "idm_conv_stage.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #ifdef IDM_TIMELINE
 // fused_b_copy_kernel: [kind of wavefront][iteration][2 k] = arrival at barrier k + 1, [2 k + 1] = departure from it
@@ -208,7 +209,7 @@ hipError_t launch_m3_split(const FusedArgs &a, int64_t B, hipStream_t s)
 // outside the map are cleared by the copy wavefronts while conv8 of that stream runs (its epilogue does not write them).
 // Partition, epilogue arithmetic, Philox counters and update are those of fused2_kernel: same results bit for bit.
 // ---------------------------------------------------------------------------------------------
-template <int NT1, int WD1, int NT2, int WD2>
+template <int NT1, int WD1, int NT2, int WD2, bool DEFER>
 __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -259,6 +260,154 @@ __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
     const int niter = nx * 4;   // stream Y ends no later than stream X
     const LaneGeo geo = make_geo(W, li);
 
+    if constexpr (DEFER) if (!copier) {
+        // Deferred epilogues: a piece's accumulators stay in registers and are finished, two values per step, inside the
+        // supersteps of the NEXT slot's MFMA loop (the other stream's conv8, or a conv9), on the plain float32 ALU:
+        //     slot 1  conv8 (X)  +  head of Y's previous band -> score Y
+        //     slot 2  conv8 (Y)  +  activation of conv8 (X)   -> mid X
+        //     slot 3  conv9 (X)  +  activation of conv8 (Y)   -> mid Y
+        //     slot 4  conv9 (Y)  +  head of X                 -> score X
+        // (a wavefront's third tile, in a lattice's nine-row top band, is finished at once).  Stores of a stream without
+        // work go to a scratch area behind the constants.
+        static_assert(BIAS_IN_ACC && NT1 == 3 && NT2 == 2, "deferred epilogues assume the bias in the accumulators");
+        using Conv1 = ConvStage<CA, CB, true, C1, NT1, 1, WD1, false, true>;
+        using Conv2 = ConvStage<C1, 0, false, C2, NT2, 1, WD2, true, true>;
+        Conv1 cs1;
+        Conv2 cs2, cs2b;
+        cs1.set_weights((const bf16x8 *)a.w1, lane);
+        cs2.set_weights((const bf16x8 *)a.w2, lane);
+        cs2b.set_weights((const bf16x8 *)a.w2, lane);
+        cs2.begin(mid(0), nullptr, c_b2, c_wh, geo, 0, R, (const bf16x8 *)a.w2, rw, lane, 0, 4, true);
+        cs2b.begin(mid(1), nullptr, c_b2, c_wh, geo, 0, R, (const bf16x8 *)a.w2, rw, lane, 0, 4, true);
+        cs2.set_slice(0);
+        cs2b.set_slice(0);
+        constexpr int ROWB = (W + 2) * SM;
+        char *const dummy = smem + 2 * STREAM + 512;            // 3 KB behind the constants
+        f32x4 kw[4];                                            // the head's weights of this lane's channels
+        f32x16 pa0, pa1, pb0, pb1;                              // the two pending pieces: one drains while the other fills
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pa0[i] = pa1[i] = pb0[i] = pb1[i] = 0.0f;
+        char *d8 = dummy;                                       // where the pending conv8 tiles go
+        float *d9 = (float *)dummy;                             // ... and the pending head values
+        float h0 = 0.f, h1 = 0.f;
+        f32x4 p4a = {0.f, 0.f, 0.f, 0.f};
+        auto nohook = [](int) {};
+        // chunk c of 16: values 2 (c & 1), 2 (c & 1) + 1 of quad (c >> 1) & 3 of pending tile c >> 3
+        auto ride8 = [&](const f32x16 &t0, const f32x16 &t1, char *dst, auto C) {
+            constexpr int c = decltype(C)::value, n = c >> 3, g = (c >> 1) & 3, hf = c & 1;
+            const f32x16 &t = n ? t1 : t0;
+            const float s0 = silu1(t[4 * g + 2 * hf]), s1 = silu1(t[4 * g + 2 * hf + 1]);
+            if constexpr (hf == 0) { h0 = s0; h1 = s1; }
+            else *(bf16x4 *)(dst + n * ROWB + 16 * g) = pack4(h0, h1, s0, s1);
+        };
+        auto ride9 = [&](const f32x16 &t0, const f32x16 &t1, float *dst, auto C) {
+            constexpr int c = decltype(C)::value, n = c >> 3, g = (c >> 1) & 3, hf = c & 1;
+            const f32x16 &t = n ? t1 : t0;
+            const float s0 = silu1(t[4 * g + 2 * hf]), s1 = silu1(t[4 * g + 2 * hf + 1]);
+            if constexpr (g == 0) p4a[2 * hf] = p4a[2 * hf + 1] = 0.0f;
+            p4a[2 * hf] += s0 * kw[g][2 * hf];           // (the same expression, hence the same contraction, as the
+            p4a[2 * hf + 1] += s1 * kw[g][2 * hf + 1];   // four-at-a-time form of the undeferred epilogue)
+            if constexpr ((c & 7) == 7) {
+                float part = (p4a[0] + p4a[1]) + (p4a[2] + p4a[3]);
+                part += __shfl_xor(part, 32, 64);
+                if (h == 0) dst[n * W] = part + c_bh[0];
+            }
+        };
+        // the chunks of superstep st of NS: [16 st / NS, 16 (st + 1) / NS)
+        auto chunks_of = [&](auto ST, auto NSC, auto &&f) {
+            constexpr int st = decltype(ST)::value, NS = decltype(NSC)::value;
+            constexpr int lo = 16 * st / NS, hi = 16 * (st + 1) / NS;
+            static_for<lo, hi>(f);
+        };
+        auto flush8 = [&](const f32x16 &t0, const f32x16 &t1, char *dst) {
+            static_for<0, 16>([&](auto C) { ride8(t0, t1, dst, C); });
+        };
+        auto flush9 = [&](const f32x16 &t0, const f32x16 &t1, float *dst) {
+            static_for<0, 16>([&](auto C) { ride9(t0, t1, dst, C); });
+        };
+        // conv8 of stream s; `ride` finishes the pending piece; the new accumulators go to (q0, q1), their target to d8
+        auto conv8 = [&](int s, Item it, f32x16 &q0, f32x16 &q1, auto &&ride, auto &&flush) {
+            if (it.act) {
+                int rlo, rhi;
+                band_geo(it, rlo, rhi);
+                char *m = mid(s);
+                cs1.begin(tile_a(s), tile_b(s), c_b1, nullptr, geo, rlo, rhi - rlo, (const bf16x8 *)a.w1, rw, lane, 0, 4, true);
+                char *nd = nullptr;
+                auto sink = [&](auto T, const f32x16 &acc, const f32x4 *, const f32x4 *, int, int r, int x, bool) {
+                    constexpr int n = decltype(T)::value;
+                    char *dst = m + __mul24(__mul24(r, W + 2) + x + 1, SM) + 8 * h;
+                    if constexpr (n == 0) { q0 = acc; nd = dst; }
+                    else if constexpr (n == 1) q1 = acc;
+                    else {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *(bf16x4 *)(dst + 16 * g) = pack4(silu1(acc[4 * g]), silu1(acc[4 * g + 1]), silu1(acc[4 * g + 2]), silu1(acc[4 * g + 3]));
+                    }
+                };
+                auto inter = [&](auto ST) { chunks_of(ST, std::integral_constant<int, Conv1::NS>{}, ride); };
+                if (cs1.f1 - cs1.f == 3) cs1.template piece<3>(cs1.f, 0, 0, sink, nohook, inter);
+                else cs1.template piece<2>(cs1.f, 0, 0, sink, nohook, inter);
+                d8 = nd;
+            } else {
+                flush();
+                d8 = dummy;
+            }
+            cs1.arm();
+        };
+        auto conv9 = [&](auto &cs, int s, Item it, f32x16 &q0, f32x16 &q1, auto &&ride, auto &&flush) {
+            if (it.act) {
+                float *sc = score(s);
+                float *nd = nullptr;
+                auto sink = [&](auto T, const f32x16 &acc, const f32x4 *, const f32x4 *, int, int r, int x, bool) {
+                    constexpr int n = decltype(T)::value;
+                    if constexpr (n == 0) { q0 = acc; nd = sc + r * W + x; }
+                    else q1 = acc;
+                };
+                auto inter = [&](auto ST) { chunks_of(ST, std::integral_constant<int, Conv2::NS>{}, ride); };
+                cs.template piece<2>(2 * rw, 0, 0, sink, nohook, inter);
+                d9 = nd;
+            } else {
+                flush();
+                d9 = (float *)dummy;
+            }
+        };
+        cs1.arm();
+        cs2.prologue();
+        __syncthreads();                       // constants, halo columns, the first bands' tiles
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kw[q] = *(const f32x4 *)(c_wh + 8 * q + 4 * h);
+        for (int n = 0; n < niter; ++n) {
+#ifdef IDM_TIMELINE
+            const int tls_n = n;
+#endif
+            const Item X = item_of(0, n), Y = item_of(1, n);
+            {   // slot 1: conv8 (X) -> (pa0, pa1); drains the head of Y's previous band (pb0, pb1)
+                float *t9 = d9;
+                conv8(0, X, pa0, pa1, [&](auto C) { ride9(pb0, pb1, t9, C); }, [&] { flush9(pb0, pb1, t9); });
+            }
+            BAR(1);
+            {   // slot 2: conv8 (Y) -> (pb0, pb1); drains conv8 (X)
+                char *t8 = d8;
+                conv8(1, Y, pb0, pb1, [&](auto C) { ride8(pa0, pa1, t8, C); }, [&] { flush8(pa0, pa1, t8); });
+            }
+            BAR(2);
+            {   // slot 3: conv9 (X) -> (pa0, pa1); drains conv8 (Y)
+                char *t8 = d8;
+                conv9(cs2, 0, X, pa0, pa1, [&](auto C) { ride8(pb0, pb1, t8, C); }, [&] { flush8(pb0, pb1, t8); });
+                cs2b.prologue();
+            }
+            BAR(3);
+            {   // slot 4: conv9 (Y) -> (pb0, pb1); drains the head of X
+                float *t9 = d9;
+                conv9(cs2b, 1, Y, pb0, pb1, [&](auto C) { ride9(pa0, pa1, t9, C); }, [&] { flush9(pa0, pa1, t9); });
+                cs2.prologue();
+            }
+            BAR(4);
+        }
+        flush9(pb0, pb1, d9);                   // the head of Y's last band
+        __syncthreads();
+        return;
+    }
     if (!copier) {
         using Conv1 = ConvStage<CA, CB, true, C1, NT1, 1, WD1, false, true>;
         using Conv2 = ConvStage<C1, 0, false, C2, NT2, 1, WD2, true, true>;
@@ -417,6 +566,33 @@ __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
     pf_load(ra[0], rb[0], item_of(0, 1));
     pf_load(ra[1], rb[1], item_of(1, 1));
     __syncthreads();                           // constants, halo columns, the first bands' tiles
+    if constexpr (DEFER) {
+        // the score tiles are complete one slot later than in the schedule below: X's after slot 4, Y's after slot 1
+        for (int n = 0; n < niter; ++n) {
+#ifdef IDM_TIMELINE
+            const int tls_n = n;
+#endif
+            const Item X = item_of(0, n), Y = item_of(1, n);
+            update(0, item_of(0, n - 1), n - 1);
+            BAR(1);
+            update(1, item_of(1, n - 1), n - 1);
+            stage_in(ra[0], rb[0], 0, item_of(0, n + 1));
+            clear_pad_rows(0, X);              // (not in the slot of X's carry copy, which reads the rows this clears)
+            BAR(2);
+            stage_in(ra[1], rb[1], 1, item_of(1, n + 1));
+            clear_pad_rows(1, Y);
+            pf_load(ra[0], rb[0], item_of(0, n + 2));
+            x_fetch(0, X, n);
+            BAR(3);
+            x_fetch(1, Y, n);
+            pf_load(ra[1], rb[1], item_of(1, n + 2));
+            BAR(4);
+        }
+        update(0, item_of(0, niter - 1), niter - 1);
+        __syncthreads();
+        update(1, item_of(1, niter - 1), niter - 1);
+        return;
+    }
     for (int n = 0; n < niter; ++n) {
 #ifdef IDM_TIMELINE
         const int tls_n = n;
@@ -450,9 +626,11 @@ hipError_t launch_b_split(const FusedArgs &a, int64_t B, hipStream_t s)
     const int slot = idm_device_slot();
     if (slot < 0) return hipErrorInvalidDevice;
     auto &st = all_st[slot];
-    auto kernel = fused_b_copy_kernel<IDM_CFG_BSPLIT>;
+    // ISINGDIFF_B_DEFER=0: epilogues right after their MFMA loops (comparison runs)
+    static const bool defer = [] { const char *e = getenv("ISINGDIFF_B_DEFER"); return !(e && e[0] == '0'); }();
+    auto kernel = defer ? fused_b_copy_kernel<IDM_CFG_BSPLIT, true> : fused_b_copy_kernel<IDM_CFG_BSPLIT, false>;
     constexpr int tile_a = ((8 / 2 + 2) * (32 / 2 + 2) * 144 + 15) & ~15, tile_b = 12 * 34 * 80, mid = 10 * 34 * 80, score = 8 * 32 * 4;
-    constexpr int lds = 2 * (tile_a + tile_b + mid + score) + (32 + 2 * 32 + 4) * 4;
+    constexpr int lds = 2 * (tile_a + tile_b + mid + score) + 512 + 3072;   // constants (400 B) and the scratch area of the deferred epilogues
     static_assert(lds <= 160 * 1024, "the tiles must fit a CU");
     if (!st.configured) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

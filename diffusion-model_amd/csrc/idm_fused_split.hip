@@ -46,7 +46,7 @@ extern "C" int idm_debug_timeline3(long long *host)
 // 36.9 KB of tiles and 1 KB of constants just fit the 160 KB of a CU.  Partition, epilogue arithmetic and results are
 // those of fused2_kernel.
 // ---------------------------------------------------------------------------------------------
-template <int NT1, int WD1, int NT2, int WD2>
+template <int NT1, int WD1, int NT2, int WD2, bool DEFER>
 __global__ __launch_bounds__(512, 1) void fused_m3_split_kernel(FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -109,6 +109,54 @@ __global__ __launch_bounds__(512, 1) void fused_m3_split_kernel(FusedArgs a)
         cs1.set_slice(sl);
         cs2.set_slice(sl);
         auto nohook = [](int) {};
+        if constexpr (DEFER) {
+            // conv7's activation and store are deferred: its accumulators stay in registers and are finished, two values
+            // per step, inside the supersteps of the next lattice's conv6 loop, on the plain float32 ALU (the staging tile
+            // is then complete one slot later, and the copy wavefronts write it out during the conv7 slot)
+            static_assert(BIAS_IN_ACC, "the deferred epilogue assumes the bias in the accumulators");
+            f32x16 pd[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pd[n][i] = 0.0f;
+            char *pdst = stage;
+            float h0 = 0.f, h1 = 0.f;
+            // chunk c of 32: values 2 (c & 1), 2 (c & 1) + 1 of quad (c >> 1) & 3 of pending tile c >> 3
+            auto ride = [&](char *dst, auto C) {
+                constexpr int c = decltype(C)::value, n = c >> 3, g = (c >> 1) & 3, hf = c & 1;
+                const float s0 = silu1(pd[n][4 * g + 2 * hf]), s1 = silu1(pd[n][4 * g + 2 * hf + 1]);
+                if constexpr (hf == 0) { h0 = s0; h1 = s1; }
+                else *(bf16x4 *)(dst + n * (W * SO) + 16 * g) = pack4(h0, h1, s0, s1);
+            };
+            auto sink = [&](auto T, const f32x16 &acc, const f32x4 *, const f32x4 *, int mt, int r, int x, bool) {
+                constexpr int n = decltype(T)::value;
+                pd[n] = acc;
+                if constexpr (n == 0) pdst = stage + __mul24(__mul24(r, W) + x, SO) + (mt * 32 + 4 * h) * 2;
+            };
+            bool pending = false;
+            if (first < nlat) cs1.prologue();
+            __syncthreads();                   // constants, halo, the first lattice's tiles
+            for (int b = first; b < nlat; b += step) {
+                char *dst = pdst;
+                // (the first lattice's ride finishes the zeros above: nothing reads the staging tile before the second's)
+                cs1.template piece<4>(j0, sl, 0, epi1, nohook, [&](auto ST) {
+                    constexpr int st = decltype(ST)::value, NS = Conv1::NS;
+                    static_for<32 * st / NS, 32 * (st + 1) / NS>([&](auto C) { ride(dst, C); });
+                });
+                cs2.prologue();
+                __syncthreads();               // B1
+                cs2.template piece<4>(j0, sl, 0, sink, nohook);
+                pending = true;
+                if (b + step < nlat) cs1.prologue();
+                __syncthreads();               // B2
+            }
+            if (pending) {
+                char *dst = pdst;
+                static_for<0, 32>([&](auto C) { ride(dst, C); });
+            }
+            __syncthreads();                   // the last lattice's staging tile
+            return;
+        }
         if (first < nlat) cs1.prologue();
         __syncthreads();                       // constants, halo, the first lattice's tiles
         for (int b = first; b < nlat; b += step) {
@@ -151,6 +199,22 @@ __global__ __launch_bounds__(512, 1) void fused_m3_split_kernel(FusedArgs a)
     pf_load(first);
     stage_in(first);
     __syncthreads();                           // constants, halo, the first lattice's tiles
+    if constexpr (DEFER) {
+        for (int b = first; b < nlat; b += step) {
+            pf_load(b + step);
+            __syncthreads();                   // B1: the previous lattice's staging tile is complete
+            stage_in(b + step);
+            if (b != first) copy_out(b - step);
+            __syncthreads();                   // B2
+        }
+        __syncthreads();                       // the last lattice's staging tile
+        if (first < nlat) {
+            int last = first;
+            while (last + step < nlat) last += step;
+            copy_out(last);
+        }
+        return;
+    }
     for (int b = first; b < nlat; b += step) {
         if (b != first) copy_out(b - step);
         pf_load(b + step);
@@ -167,7 +231,9 @@ __global__ __launch_bounds__(512, 1) void fused_m3_split_kernel(FusedArgs a)
 
 hipError_t launch_m3_split(const FusedArgs &a, int64_t B, hipStream_t s)
 {
-    auto kernel = fused_m3_split_kernel<4, 2, 4, 3>;
+    // ISINGDIFF_M3_DEFER=0: conv7's epilogue right after its MFMA loop (comparison runs)
+    static const bool defer = [] { const char *e = getenv("ISINGDIFF_M3_DEFER"); return !(e && e[0] == '0'); }();
+    auto kernel = defer ? fused_m3_split_kernel<4, 2, 4, 3, true> : fused_m3_split_kernel<4, 2, 4, 3, false>;
     constexpr int tile_a = ((16 / 2 + 2) * (16 / 2 + 2) * 272 + 15) & ~15, tile_b = 20 * 18 * 144, mid = 18 * 18 * 144,
                   stage = 16 * 16 * 144;
     constexpr int lds = tile_a + tile_b + mid + stage + (64 + 64) * 4;

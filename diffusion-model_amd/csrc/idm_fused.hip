@@ -46,11 +46,20 @@
 namespace {
 
 // First layer (Cin = 1): K = 9 taps in one MFMA step; x = hi + lo in bf16, two MFMAs per tile.
-// xs: float32 tile [(rows)][W+2].  wfirst: one A fragment (lane l: cout l&31, k = 8*(l>>5)+j -> tap k).
+// xs: tile [(rows)][W+2] of (hi, lo) bf16 pairs, split once per pixel when the band is staged (split_state) instead of
+// once per pixel and tap here.  wfirst: one A fragment (lane l: cout l&31, k = 8*(l>>5)+j -> tap k).
+DEVI uint32_t split_state(float v)
+{
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    return (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+}
+
 template <class Epi>
-DEVI void conv_first_stage(const float *xs, const float *c0, int W, int r0, int npix, const bf16x8 *__restrict__ wfirst,
+DEVI void conv_first_stage(const uint32_t *xs, const float *c0, int W, int r0, int npix, const bf16x8 *__restrict__ wfirst,
                            int wave, int lane, Epi &&epi)
 {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
     f32x4 k0[4], k1[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -65,8 +74,8 @@ DEVI void conv_first_stage(const float *xs, const float *c0, int W, int r0, int 
         const bool valid = p < npix;
         const int pc = valid ? p : 0;
         const int r = pc / W + r0, x = pc - (r - r0) * W;
-        const float *q = xs + r * Wp2 + x;
-        float v[8];
+        const uint32_t *q = xs + r * Wp2 + x;
+        uint32_t v[8];
         if (h == 0) {
             v[0] = q[0]; v[1] = q[1]; v[2] = q[2];
             v[3] = q[Wp2]; v[4] = q[Wp2 + 1]; v[5] = q[Wp2 + 2];
@@ -74,19 +83,19 @@ DEVI void conv_first_stage(const float *xs, const float *c0, int W, int r0, int 
         } else {
             v[0] = q[2 * Wp2 + 2];
 #pragma unroll
-            for (int j = 1; j < 8; ++j) v[j] = 0.0f;
+            for (int j = 1; j < 8; ++j) v[j] = 0u;
         }
-        bf16x8 hi, lo;
+        u32x4 hi, lo;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            hi[j] = (__bf16)v[j];
-            lo[j] = (__bf16)(v[j] - (float)hi[j]);
+        for (int j = 0; j < 4; ++j) {
+            hi[j] = __builtin_amdgcn_perm(v[2 * j + 1], v[2 * j], 0x05040100u);   // the low halves of the two words
+            lo[j] = __builtin_amdgcn_perm(v[2 * j + 1], v[2 * j], 0x07060302u);   // the high halves
         }
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = BIAS_IN_ACC ? k0[i >> 2][i & 3] : 0.0f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hi, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, lo, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, hi), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, lo), acc, 0, 0, 0);
         epi(acc, k0, k1, 0, r, x, valid);
     }
 }
@@ -235,13 +244,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
         asm volatile("" : "+v"(tid));
         __builtin_assume(tid >= 0 && tid < WGS);
         if constexpr (MODE1 == M1_FIRST) {
-            float *xs = (float *)lds_in;
+            uint32_t *xs = (uint32_t *)lds_in;
 #pragma unroll
             for (int k = 0; k < NPA; ++k) {
                 const int i = tid + k * WGS, t = i / W, c = i - t * W;
-                if (t < R + 4) xs[t * (W + 2) + c + 1] = rx[k];
+                if (t < R + 4) xs[t * (W + 2) + c + 1] = split_state(rx[k]);
             }
-            for (int i = tid; i < (R + 4) * 2; i += WGS) xs[(i >> 1) * (W + 2) + (i & 1) * (W + 1)] = 0.0f;
+            for (int i = tid; i < (R + 4) * 2; i += WGS) xs[(i >> 1) * (W + 2) + (i & 1) * (W + 1)] = 0u;
         } else if constexpr (MODE1 == M1_PLAIN) {
             ra.store(tile_a, W, R + 4, tid);
         } else {
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
 #endif
             };
             if constexpr (MODE1 == M1_FIRST)
-                conv_first_stage((const float *)lds_in, c_b1, W, rlo, (rhi - rlo) * W, (const bf16x8 *)a.w1, wave, lane, epi1);
+                conv_first_stage((const uint32_t *)lds_in, c_b1, W, rlo, (rhi - rlo) * W, (const bf16x8 *)a.w1, wave, lane, epi1);
             else
                 cs1.run(epi1, TLHOOK(10));
         }

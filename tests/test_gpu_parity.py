@@ -415,9 +415,11 @@ def test_bf16_update_is_the_canonical_expression_of_its_score(gpu_real, L):
 def test_copy_wavefront_kernels_are_bit_identical_to_the_four_wavefront_ones(gpu_real, tmp_path):
     """At L=32 the bf16 sampler runs conv6 + conv7 and conv8 + conv9 + head + update in workgroups of eight wavefronts
     (four for the MFMA loops and epilogues, four for tile copies, noise draw and update; csrc/idm_fused_split.hip).
-    ISINGDIFF_M3_SPLIT=0 / ISINGDIFF_B_SPLIT=0 select the four-wavefront kernels.  Same partition, arithmetic and Philox
-    counters: the final state must be the same bit for bit.  Odd and small batches cover workgroups whose second lattice
-    stream runs dry.  (The switches are read once per process, hence the child processes.)"""
+    ISINGDIFF_M3_SPLIT=0 / ISINGDIFF_B_SPLIT=0 select the four-wavefront kernels; by default the eight-wavefront kernels also
+    finish a piece's epilogue inside the next MFMA loop (ISINGDIFF_M3_DEFER=0 / ISINGDIFF_B_DEFER=0: right after its own).
+    Same partition, arithmetic and Philox counters: the final state must be the same bit for bit.  Odd and small batches
+    cover workgroups whose second lattice stream runs dry, 2 049 a workgroup with five lattices in one stream and four in the
+    other.  (The switches are read once per process, hence the child processes.)"""
     import os, subprocess, sys
     from isingdiff.sampler import sample, beta_schedule
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -426,16 +428,19 @@ def test_copy_wavefront_kernels_are_bit_identical_to_the_four_wavefront_ones(gpu
         f"sys.path.insert(0, {os.path.join(root, 'diffusion-model_amd')!r})\n"
         "from isingdiff import load_model, sample, beta_schedule\n"
         f"m = load_model({os.path.join(root, 'weights', 'b_diffusion_model_2d_ising_realspace_unet.keras')!r}, device=0, precision='bf16')\n"
-        "for B in (1, 5, 777):\n"
+        "for B in (1, 5, 777, 2049):\n"
         "    r = sample(m, B, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision='bf16', keep_state=True)\n"
         "    np.save(os.path.join(sys.argv[1], f'{sys.argv[2]}{B}.npy'), r.x_final.cpu().numpy())\n")
-    assert "ISINGDIFF_M3_SPLIT" not in os.environ and "ISINGDIFF_B_SPLIT" not in os.environ
-    for tag, env in (("m", {"ISINGDIFF_M3_SPLIT": "0"}), ("b", {"ISINGDIFF_B_SPLIT": "0"})):
+    switches = ("ISINGDIFF_M3_SPLIT", "ISINGDIFF_B_SPLIT", "ISINGDIFF_M3_DEFER", "ISINGDIFF_B_DEFER")
+    assert not any(k in os.environ for k in switches)
+    variants = (("m", {"ISINGDIFF_M3_SPLIT": "0"}), ("b", {"ISINGDIFF_B_SPLIT": "0"}),
+                ("d", {"ISINGDIFF_M3_DEFER": "0", "ISINGDIFF_B_DEFER": "0"}))
+    for tag, env in variants:
         subprocess.run([sys.executable, "-c", code, str(tmp_path), tag], check=True, env=dict(os.environ, **env), timeout=240)
-    for B in (1, 5, 777):
+    for B in (1, 5, 777, 2049):
         want = sample(gpu_real, B, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision="bf16", keep_state=True)
         want = want.x_final.cpu().numpy()
-        for tag in ("m", "b"):
+        for tag, _ in variants:
             got = np.load(tmp_path / f"{tag}{B}.npy")
             assert np.isfinite(got).all()
             assert np.array_equal(got, want), (tag, B)

@@ -154,6 +154,107 @@ __global__ __launch_bounds__(256) void bf_gn_apply_kernel(const float *__restric
     }
 }
 
+// bf16 convolution mode: GroupNormalization(groups=8) + swish of one sample in ONE workgroup, the sample's values held in
+// registers between the statistics and the apply (x is read once, 4 bytes in and 2 bytes out per value, instead of three
+// reads and one write by the two kernels above).  Thread t owns quads t, t + THREADS, ... (a quad = four consecutive
+// channels of a pixel); THREADS is a multiple of the C / 4 quads of a pixel, so all of a thread's quads are the same four
+// channels, hence one group (a group is a multiple of four channels wide).  Mean, then variance of the centred values,
+// float32, partial sums folded per group through LDS; swish through the hardware exp2 / rcp.  Not the parity mode's
+// summation order: used only where the output is rounded to bf16.
+template <int THREADS, int NV>
+__global__ __launch_bounds__(THREADS) void bf_gn_fused_bf16_kernel(const float *__restrict__ x, int HW, int C,
+                                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                   __bf16 *__restrict__ y)
+{
+    __shared__ float part[THREADS];
+    __shared__ float stat[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Q = C >> 2, Qg = Q >> 3, nq = HW * Q;          // quads per pixel, per group and pixel, per sample
+    const int c4 = tid % Q, grp = c4 / Qg;
+    const float *xb = x + (size_t)blockIdx.x * HW * C;
+    f32x4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int q = tid + k * THREADS;
+        v[k] = q < nq ? *(const f32x4 *)(xb + (size_t)q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // sum over the threads of each group: wavefront w folds groups w, w + waves, ...; entry e of group g is thread
+    // (e / Qg) * Q + g * Qg + e % Qg
+    auto group_sums = [&](float mine) {
+        part[tid] = mine;
+        __syncthreads();
+        for (int g = wave; g < 8; g += THREADS / 64) {
+            float s = 0.0f;
+            for (int e = lane; e < THREADS / 8; e += 64) s += part[(e / Qg) * Q + g * Qg + e % Qg];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (lane == 0) stat[g] = s;
+        }
+        __syncthreads();
+        const float r = stat[grp];
+        __syncthreads();
+        return r;
+    };
+    const float n = (float)(HW * (C >> 3));
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    const float mean = group_sums(s) / n;
+    float qd = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (tid + k * THREADS < nq) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[k][j] - mean;
+                qd = __builtin_fmaf(d, d, qd);
+            }
+        }
+    }
+    const float inv = rsqrt_canon(group_sums(qd) / n + 1e-3f);
+    const f32x4 gm = *(const f32x4 *)(gamma + 4 * c4), bt = *(const f32x4 *)(beta + 4 * c4);
+    float a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] = inv * gm[j];
+        b[j] = bt[j] - mean * a[j];
+    }
+    __bf16 *yb = y + (size_t)blockIdx.x * HW * C;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int q = tid + k * THREADS;
+        if (q < nq) {
+            float r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = __builtin_fmaf(v[k][j], a[j], b[j]);
+                r[j] = z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
+            }
+            *(bf16x4 *)(yb + (size_t)q * 4) = bf16x4{(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]};
+        }
+    }
+}
+
+// Launches the fused kernel when a (threads, quads per thread) instance covers the sample; false: the caller takes the
+// two-kernel path.
+template <int THREADS, int NV>
+bool gn_fused_try(const float *x, int64_t B, int HW, int C, const float *gamma, const float *beta, __bf16 *y, hipStream_t s)
+{
+    const int Q = C / 4;
+    if (THREADS % Q != 0 || (int64_t)HW * Q > (int64_t)THREADS * NV) return false;
+    hipLaunchKernelGGL((bf_gn_fused_bf16_kernel<THREADS, NV>), dim3((unsigned)B), dim3(THREADS), 0, s, x, HW, C, gamma, beta, y);
+    return true;
+}
+
+bool gn_fused_bf16(const float *x, int64_t B, int HW, int C, const float *gamma, const float *beta, __bf16 *y, hipStream_t s)
+{
+    if (C % 32 != 0 || B > 0x7fffffff) return false;   // eight groups of a multiple of four channels
+    return gn_fused_try<256, 4>(x, B, HW, C, gamma, beta, y, s) || gn_fused_try<256, 8>(x, B, HW, C, gamma, beta, y, s) ||
+           gn_fused_try<256, 16>(x, B, HW, C, gamma, beta, y, s) || gn_fused_try<256, 28>(x, B, HW, C, gamma, beta, y, s) ||
+           gn_fused_try<768, 4>(x, B, HW, C, gamma, beta, y, s) || gn_fused_try<768, 13>(x, B, HW, C, gamma, beta, y, s) ||
+           gn_fused_try<768, 25>(x, B, HW, C, gamma, beta, y, s) || gn_fused_try<1024, 20>(x, B, HW, C, gamma, beta, y, s);
+}
+
 // out = (conv1x1(x) + bias) + h  (the ResBlock's projected shortcut, :188-192); w == nullptr: out = x + h.
 __global__ __launch_bounds__(256) void bf_shortcut_kernel(const float *__restrict__ x, int Cin, const float *__restrict__ w,
                                                           const float *__restrict__ bias, const float *__restrict__ h,
@@ -343,6 +444,7 @@ int time_vectors(idm_bitflip *m, const float *emb_host, int rows, hipStream_t s)
 void gn_silu(const float *x, int64_t B, int HW, int C, const float *gamma, const float *beta, float *ab, float *y, bool half,
              hipStream_t s)
 {
+    if (half && gn_fused_bf16(x, B, HW, C, gamma, beta, (__bf16 *)y, s)) return;
     hipLaunchKernelGGL(bf_gn_stats_kernel, dim3((unsigned)((B * 8 + 3) / 4)), dim3(256), 0, s, x, B, HW, C, gamma, beta, ab);
     const int64_t n = B * HW * C;
     if (half)

@@ -461,8 +461,8 @@ void conv3(const float *in, int64_t B, int H, int W, int Cin, const void *wpack,
     a.in0 = in; a.in1 = nullptr; a.C0 = Cin; a.C1 = 0; a.H = H; a.W = W; a.B = B; a.wpack = wpack; a.bias = bias;
     a.scale = nullptr; a.shift = nullptr; a.tadd = tadd; a.out = out; a.Cout = Cout; a.mode = CONV_PLAIN; a.silu = 0;
     a.out_f32 = 1;
-    if (half) launch_conv_bf16(a, s);
-    else launch_conv_f32(a, s);
+    if (!half) launch_conv_f32(a, s);
+    else if (!launch_conv_tile_bf16(a, s)) launch_conv_bf16(a, s);   // (wider maps and other channel counts: per-layer kernel)
 }
 
 // ResBlock (:168-193).  ta: >= B*H*W*max(Cin,width) floats, tbuf: >= B*H*W*width floats.

@@ -90,6 +90,10 @@ void launch_cast_bf16_to_f32(const void *in, float *out, int64_t n, hipStream_t 
 // ---- bf16 kernels (idm_fast.hip) ----
 void launch_conv_bf16(const ConvArgs &a, hipStream_t s);
 
+// LDS-tiled kernel for plain convolutions on maps at most 32 wide with raw float32 output (idm_tileconv.hip); false: shape
+// not covered, nothing launched
+bool launch_conv_tile_bf16(const ConvArgs &a, hipStream_t s);
+
 // ---- fused two-convolution band kernels (idm_fused.hip) ----
 enum FusedKind { FK_A = 0, FK_M1 = 1, FK_M2 = 2, FK_M3 = 3, FK_B = 4 };
 

@@ -273,6 +273,48 @@ __global__ __launch_bounds__(256) void bf_shortcut_kernel(const float *__restric
     out[i] = __fadd_rn(__fadd_rn(acc, bias[co]), h[i]);
 }
 
+// bf16 convolution mode: the projected shortcut out = (conv1x1(x) + bias) + h on the bf16 matrix cores.  One wavefront =
+// 32 pixels x all output channels; x is read as float32 (eight consecutive channels per lane and step) and rounded to bf16
+// on the way into the MFMA; wpack: bf16 A fragments [c / 16][Cout / 32][lane][8] (the centre tap of the 3x3 packing).
+// HBM-bound: x, h in and out out once each.
+template <int MT>
+__global__ __launch_bounds__(256) void bf_shortcut_mfma_kernel(const float *__restrict__ x, int Cin, const bf16x8 *__restrict__ wpack,
+                                                               const float *__restrict__ bias, const float *__restrict__ hres,
+                                                               float *__restrict__ out, int64_t npix)
+{
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile * 32 >= npix) return;
+    const int64_t p = tile * 32 + li;
+    const bool pv = p < npix;
+    const float *xp = x + (pv ? p : 0) * Cin + 8 * h;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+    const int ncg = Cin >> 4;
+    for (int cg = 0; cg < ncg; ++cg) {
+        const f32x4 v0 = *(const f32x4 *)(xp + 16 * cg), v1 = *(const f32x4 *)(xp + 16 * cg + 4);
+        const bf16x8 bv = {(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3],
+                           (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wpack[((size_t)cg * MT + m) * 64 + lane], bv, acc[m], 0, 0, 0);
+    }
+    if (!pv) return;
+    const int Cout = MT * 32;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = m * 32 + 8 * g + 4 * h;
+            const f32x4 b4 = *(const f32x4 *)(bias + co), r4 = *(const f32x4 *)(hres + p * Cout + co);
+            const f32x4 z = {acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
+            *(f32x4 *)(out + p * Cout + co) = (z + b4) + r4;
+        }
+}
+
 __global__ __launch_bounds__(256) void bf_maxpool_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t B,
                                                          int H, int W, int C)
 {
@@ -352,6 +394,7 @@ struct idm_bitflip {
     const float *t[IDM_BITFLIP_NTENSOR] = {};   // device copies, Keras layouts
     void *c1_pack[NBLK] = {}, *c2_pack[NBLK] = {}, *s_pack[NBLK] = {};
     void *c1_pack16[NBLK] = {}, *c2_pack16[NBLK] = {};   // bf16 fragments of the 3x3 kernels
+    void *s_pack16[NBLK] = {};                             // ... and of the 1x1 shortcut kernels
     int precision = IDM_FP32;
     float *emb_dev = nullptr;   // (T, EMB) scratch for the embedding rows
     int emb_cap = 0;
@@ -476,7 +519,17 @@ void resblock(idm_bitflip *m, int i, const float *x, int64_t B, int H, int W, co
     gn_silu(tbuf, B, HW, Cw, m->t[tb(i, K_G2_G)], m->t[tb(i, K_G2_B)], ab, ta, half, s);
     conv3(ta, B, H, W, Cw, half ? m->c2_pack16[i] : m->c2_pack[i], m->t[tb(i, K_C2_B)], nullptr, tbuf, Cw, half, s);
     const int64_t npix = B * HW;
-    if (m->s_pack[i]) {
+    if (half && m->s_pack16[i] && Cw % 32 == 0 && Cw <= 128 && Cin % 16 == 0) {
+        const unsigned grid = (unsigned)((npix + 127) / 128);
+        const bf16x8 *wp = (const bf16x8 *)m->s_pack16[i];
+        const float *sb = m->t[tb(i, K_S_B)];
+        switch (Cw / 32) {
+        case 1: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<1>, dim3(grid), dim3(256), 0, s, x, Cin, wp, sb, (const float *)tbuf, out, npix); break;
+        case 2: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<2>, dim3(grid), dim3(256), 0, s, x, Cin, wp, sb, (const float *)tbuf, out, npix); break;
+        case 3: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<3>, dim3(grid), dim3(256), 0, s, x, Cin, wp, sb, (const float *)tbuf, out, npix); break;
+        default: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<4>, dim3(grid), dim3(256), 0, s, x, Cin, wp, sb, (const float *)tbuf, out, npix); break;
+        }
+    } else if (m->s_pack[i]) {
         // projected shortcut (:188-192) on the matrix cores: the centre tap alone is a 1x1 convolution with the
         // same k-ordered chain; out = (chain + bias) + h
         ConvArgs a = {};
@@ -591,6 +644,21 @@ int idm_bitflip_create(idm_bitflip **out, int device, const idm_bitflip_desc *d)
             float *pd = nullptr;
             rc = bf_upload(m, pk.data(), pk.size(), &pd);
             m->s_pack[blk] = pd;
+            if (rc == IDM_OK && kCin[blk] % 16 == 0) {
+                // the centre tap of a 3x3 kernel that is zero elsewhere, packed like the 3x3 kernels: [tap][c/16][mt][lane][8]
+                const int ci = kCin[blk], co = kWidth[blk];
+                std::vector<float> k3((size_t)9 * ci * co, 0.0f);
+                std::copy(d->tensors[i], d->tensors[i] + (size_t)ci * co, k3.begin() + (size_t)4 * ci * co);
+                const std::vector<uint16_t> ph = idm_pack_weights_bf16(k3.data(), ci, co);
+                const size_t per_tap = (size_t)ci * co;
+                void *hd = nullptr;
+                if (hipMalloc(&hd, per_tap * 2) != hipSuccess) rc = idm_set_error(IDM_ERR_NOMEM, "bit-flip weight allocation failed");
+                else {
+                    m->owned.push_back(hd);
+                    (void)hipMemcpy(hd, ph.data() + 4 * per_tap, per_tap * 2, hipMemcpyHostToDevice);
+                    m->s_pack16[blk] = hd;
+                }
+            }
         }
     }
     if (rc != IDM_OK) {

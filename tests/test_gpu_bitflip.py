@@ -117,8 +117,10 @@ def fast(setup):
     return bitflip.BitflipModel(model.weights, device=0, time_step=100, precision="bf16")
 
 
-@pytest.mark.parametrize("hw", [(28, 28), (12, 20)])
+@pytest.mark.parametrize("hw", [(28, 28), (12, 20), (8, 40)])
 def test_bf16_forward_within_tolerance(setup, fast, hw):
+    """(28, 28) and (12, 20): LDS-tiled convolutions, whole maps and bands; (8, 40): wider than a 32-pixel tile row, the
+    per-layer convolution kernel.  GroupNorm + swish in one workgroup per sample and the MFMA shortcuts in all three."""
     bitflip, model, ref = setup
     H, W = hw
     rs = np.random.RandomState(6)

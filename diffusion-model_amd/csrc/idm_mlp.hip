@@ -120,8 +120,11 @@ __global__ __launch_bounds__(MAXW) void mlp_step_kernel(MlpArgs a)
 // state stays float32 in global memory and is updated by the lanes that hold the last layer's outputs;
 // noise counters are those of the float32 kernel, so both paths draw the same normals.
 // ---------------------------------------------------------------------------------------------
-constexpr int FNT = 2;              // MFMA N tiles (of 32 samples) per workgroup
-constexpr int FS = 32 * FNT;        // samples per workgroup
+// Two instances.  <4, true>: 128 samples per workgroup (every weight fragment feeds four sample tiles: half the weight
+// traffic per sample of the other instance), one activation buffer rewritten in place - every wavefront owns at most one
+// pair of cout tiles, keeps the layer's outputs in its accumulators, and all of them are stored only after a barrier that
+// follows the last read of the inputs; needs every layer to have at most 16 cout tiles (512 outputs).  <2, false>: 64
+// samples, two buffers, any width.
 constexpr int FWG = 512;
 
 struct MlpFastArgs {
@@ -147,8 +150,10 @@ DEVI float fast_tanh(float z)
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+template <int FNT, bool INPLACE>
 __global__ __launch_bounds__(FWG, 1) void mlp_step_bf16_kernel(MlpFastArgs a)
 {
+    constexpr int FS = 32 * FNT;        // samples per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = lane & 31, h = lane >> 5;
@@ -173,16 +178,17 @@ __global__ __launch_bounds__(FWG, 1) void mlp_step_bf16_kernel(MlpFastArgs a)
     for (int l = 0; l < a.n_layers; ++l) {
         const int KT = a.kt[l], MT = a.mt[l];
         const bool last = l == a.n_layers - 1;
+        const int nxt = INPLACE ? 0 : cur ^ 1;
         const char *src = smem + cur * bufsz + nl * str + h * 16;
-        char *dst = smem + (cur ^ 1) * bufsz + nl * str;
+        char *dst = smem + nxt * bufsz + nl * str;
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(a.w[l]), 0, (unsigned)(KT * MT * 1024), 0x00020000);
-        for (int m0 = wave * 2; m0 < MT; m0 += 2 * (FWG / 64)) {
+        f32x16 acc[2][FNT];
+        auto compute = [&](int m0) {
             const bool two = m0 + 1 < MT;
             unsigned wo = (unsigned)((m0 * 64 + lane) * 16);
             asm volatile("" : "+v"(wo));   // keeps the unrolled fetches inside the loop
             const unsigned wo1 = two ? wo + 1024u : 0x80000000u;   // odd tile count: the second tile reads zeros
             const unsigned kstep = (unsigned)MT * 1024u;
-            f32x16 acc[2][FNT];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(FWG, 1) void mlp_step_bf16_kernel(MlpFastArgs a)
             // RING-slot register ring: the fragments of k-step kt + RING are requested as soon as those of kt are
             // used.  KT is a multiple of RING and the loop body has no branches (requests past the end re-read the
             // last fragments), so the waits inside it stay counted instead of draining the queue.
-            constexpr int RING = 4;
+            constexpr int RING = FNT > 2 ? 2 : 4;   // (measured: 2, 4 and 7 slots run alike; deeper rings spill beside 128 accumulators)
             bf16x8 w0[RING], w1[RING];
 #pragma unroll
             for (int j = 0; j < RING; ++j) { w0[j] = wload(wo, j); w1[j] = wload(wo1, j); }
@@ -214,12 +220,16 @@ __global__ __launch_bounds__(FWG, 1) void mlp_step_bf16_kernel(MlpFastArgs a)
                     __builtin_amdgcn_sched_barrier(0);   // keeps each k-step's requests in place (the scheduler would sink them all)
                 }
             }
-            // epilogue: lane (sample nl, half h) holds couts 32*m + 8g + 4h + i
+        };
+        auto epilogue = [&](int m0) {
+            const bool two = m0 + 1 < MT;
+            // lane (sample nl, half h) holds couts 32*m + 8g + 4h + i
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 if (t == 1 && !two) break;
 #pragma unroll
               for (int q = 0; q < FNT; ++q) {
+                __builtin_amdgcn_sched_barrier(0);   // one tile at a time: hoisting every tile's loads ahead spills
                 const f32x16 &ac = acc[t][q];
                 const int sn = q * 32 + nl;        // sample within the workgroup
                 char *dstq = dst + q * 32 * str;
@@ -251,7 +261,12 @@ __global__ __launch_bounds__(FWG, 1) void mlp_step_bf16_kernel(MlpFastArgs a)
 #pragma unroll
                                     for (int i = 0; i < 4; ++i) zz[i] = zv[i];
                                 } else {
-                                    normal4(a.ph.seed, a.ph.first_global_index + b0 + sn, (uint32_t)(c >> 2), a.ph.t, zz);
+                                    // (the counter is made opaque here: the draw depends on nothing the layers compute, and
+                                    // the optimiser would otherwise hoist all of a wavefront's draws to the top of the
+                                    // kernel and hold them in registers through every layer)
+                                    uint32_t quad = (uint32_t)(c >> 2);
+                                    asm volatile("" : "+v"(quad));
+                                    normal4(a.ph.seed, a.ph.first_global_index + b0 + sn, quad, a.ph.t, zz);
                                 }
                             }
 #pragma unroll
@@ -266,17 +281,28 @@ __global__ __launch_bounds__(FWG, 1) void mlp_step_bf16_kernel(MlpFastArgs a)
                 }
               }
             }
+        };
+        if constexpr (INPLACE) {
+            const int m0 = wave * 2;             // (host-checked: MT <= 16, one pair of cout tiles per wavefront at most)
+            if (m0 < MT) compute(m0);
+            __syncthreads();                     // every wavefront has read the layer's inputs
+            if (m0 < MT) epilogue(m0);
+        } else {
+            for (int m0 = wave * 2; m0 < MT; m0 += 2 * (FWG / 64)) {
+                compute(m0);
+                epilogue(m0);
+            }
         }
         // layers narrower than the padded row: the k range [32*MT, kp) of the next input must read as zero
         if (!last) {
             const int c0 = MT * 32;
             for (int i = tid; i < FS * ((a.kp - c0) >> 2); i += FWG) {
                 const int per = (a.kp - c0) >> 2, s = i / per, q = i - s * per;
-                *(bf16x4 *)(smem + (cur ^ 1) * bufsz + s * str + (c0 + q * 4) * 2) = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+                *(bf16x4 *)(smem + nxt * bufsz + s * str + (c0 + q * 4) * 2) = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
             }
         }
         __syncthreads();
-        cur ^= 1;
+        cur = nxt;
     }
 }
 
@@ -334,16 +360,22 @@ bool fast_ok(const idm_mlp *m)
 
 int launch_fast(const idm_mlp *m, const MlpFastArgs &a, hipStream_t s)
 {
-    const size_t lds = (size_t)2 * FS * (m->kp * 2 + 16);   // 114 KB for the saved model: one workgroup per CU
-    static thread_local bool configured[IDM_MAX_DEVICES] = {};
+    const size_t row = (size_t)m->kp * 2 + 16;
+    bool inplace = 128 * row <= 160 * 1024;   // 114 KB for the saved model either way: one workgroup per CU
+    for (int i = 0; i < m->n_layers; ++i) inplace = inplace && m->mt[i] <= 16;
+    static thread_local bool configured[IDM_MAX_DEVICES][2] = {};
     const int slot = idm_device_slot();
     if (slot < 0) return idm_set_error(IDM_ERR_HIP, "no current device");
-    if (!configured[slot]) {
-        if (hipFuncSetAttribute((const void *)mlp_step_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    const void *kernel = inplace ? (const void *)mlp_step_bf16_kernel<4, true> : (const void *)mlp_step_bf16_kernel<2, false>;
+    if (!configured[slot][inplace]) {
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return idm_set_error(IDM_ERR_HIP, "hipFuncSetAttribute failed");
-        configured[slot] = true;
+        configured[slot][inplace] = true;
     }
-    hipLaunchKernelGGL(mlp_step_bf16_kernel, dim3((unsigned)((a.B + FS - 1) / FS)), dim3(FWG), lds, s, a);
+    if (inplace)
+        hipLaunchKernelGGL((mlp_step_bf16_kernel<4, true>), dim3((unsigned)((a.B + 127) / 128)), dim3(FWG), 128 * row, s, a);
+    else
+        hipLaunchKernelGGL((mlp_step_bf16_kernel<2, false>), dim3((unsigned)((a.B + 63) / 64)), dim3(FWG), 2 * 64 * row, s, a);
     return IDM_OK;
 }
 

@@ -29,7 +29,7 @@ for path in sys.argv[1:]:
                 cnt[(path, k)] += 1
 for k, c in acc.items():
     paths = [p for (p, kk) in dur if kk == k]
-    if not paths or not any(w in k for w in ("fused", "strip", "irfft", "conv")):
+    if not paths or not any(w in k for w in ("fused", "strip", "irfft", "conv", "mlp", "bf_")):
         continue
     p0 = paths[0]
     d, n = dur[(p0, k)], cnt[(p0, k)]

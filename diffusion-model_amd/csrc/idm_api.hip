@@ -166,6 +166,7 @@ struct Plan {
     bool fused;          // bf16 band kernels usable for this shape
     int R[5];            // band rows per fused kernel
     bool layers;         // bf16, 2-channel / BatchNorm model: layers 1..9 run as strip kernels (BatchNorm folded)
+    bool lpair[5];       // ... except these pairs (FK_M1, FK_M2, FK_M3), which run as fused band kernels with R[] rows
     bool strip[5];       // this pair of layers runs as single-convolution strip kernels instead
     int sR[SK_COUNT], sWS[SK_COUNT];   // band rows / strip columns of the strip kernels
 };
@@ -225,7 +226,7 @@ Plan make_plan(const idm_model *m, int H, int W, int precision)
     p.Hp = H + (4 - H % 4) % 4;
     p.Wp = W + (4 - W % 4) % 4;
     p.es = precision == IDM_BF16 ? 2 : 4;
-    for (int k = 0; k < 5; ++k) { p.R[k] = 0; p.strip[k] = false; }
+    for (int k = 0; k < 5; ++k) { p.R[k] = 0; p.strip[k] = false; p.lpair[k] = false; }
     // the fused band kernels cover the real-space model (one state channel, no BatchNorm)
     p.fused = precision == IDM_BF16 && m->C == 1 && !m->bn && m->use_fused && m->w_first_pack != nullptr;
     if (p.fused) {
@@ -257,6 +258,13 @@ Plan make_plan(const idm_model *m, int H, int W, int precision)
             if (sk == SK_CONV9) continue;
             p.sR[sk] = pick_strip_rows(sk, hh[lvl[sk]], ww[lvl[sk]], &p.sWS[sk]);
             if (p.sR[sk] == 0) p.layers = false;
+        }
+        // the three inner pairs have the real-space model's shapes: fused band kernels where a band of at least 8 rows
+        // (or the whole map) fits
+        const int lv[5] = {0, 1, 2, 1, 0};
+        for (int k = FK_M1; k <= FK_M3; ++k) {
+            p.R[k] = p.layers ? pick_band_rows(k, hh[lv[k]], ww[lv[k]]) : 0;
+            p.lpair[k] = p.R[k] > 0 && (p.R[k] >= 8 || p.R[k] >= hh[lv[k]]);
         }
     }
     // Workspace: one buffer per kind, sized for what the selected schedule stores in it.  The fused schedule
@@ -568,13 +576,46 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
                   [&] { e = launch_strip(sk, a, s); });
             if (e != hipSuccess) rc = fail(IDM_ERR_HIP, std::string("launch ") + name + ": " + hipGetErrorString(e));
         };
+        // a pair of layers as one fused band kernel (same weights, bias and operand order as the two strip launches)
+        auto pair = [&](int kind, int l1, const void *in_a, const void *in_b, void *out, void *out_pool, int H, int W) {
+            if (rc != IDM_OK) return;
+            FusedArgs a = {};
+            a.w1 = m->bn ? m->wpack_fold[l1] : m->wpack_bf16[l1];
+            a.b1 = m->bn ? m->bias_fold[l1] : m->bias[l1];
+            a.w2 = m->bn ? m->wpack_fold[l1 + 1] : m->wpack_bf16[l1 + 1];
+            a.b2 = m->bn ? m->bias_fold[l1 + 1] : m->bias[l1 + 1];
+            a.tadd1 = l1 == 4 ? tadd : nullptr;
+            a.in_a = in_a; a.in_b = in_b; a.out = out; a.out_pool = out_pool;
+            a.H = H; a.W = W; a.R = p.R[kind]; a.nbands = (H + a.R - 1) / a.R;
+            a.Hx = p.H; a.Wx = p.W; a.B = Bc;
+            fused_lds_bytes(kind, W, a.R, &a.lds_in_bytes, &a.lds_mid_bytes);
+            char name[32];
+            snprintf(name, sizeof(name), "fused_conv%d,%d", l1, l1 + 1);
+            const double px = (double)Bc * H * W;
+            hipError_t e = hipSuccess;
+            timed(m, name, 2.0 * 9 * (m->cin[l1] * m->cout[l1] + m->cin[l1 + 1] * m->cout[l1 + 1]) * px,
+                  px * (m->cin[l1] + m->cout[l1 + 1]) * 2, s, [&] { e = launch_fused(kind, a, Bc, s); });
+            if (e != hipSuccess) rc = fail(IDM_ERR_HIP, std::string("launch ") + name + ": " + hipGetErrorString(e));
+        };
         strip(SK_CONV1, 1, a0, nullptr, s1, a4, Hp, Wp);
-        strip(SK_CONV2, 2, a4, nullptr, a2, nullptr, Hp / 2, Wp / 2);
-        strip(SK_CONV3, 3, a2, nullptr, s2, a5, Hp / 2, Wp / 2);
-        strip(SK_CONV4, 4, a5, nullptr, a4, nullptr, Hp / 4, Wp / 4);
-        strip(SK_CONV5, 5, a4, nullptr, a5, nullptr, Hp / 4, Wp / 4);
-        strip(SK_CONV6, 6, a5, s2, a6, nullptr, Hp / 2, Wp / 2);
-        strip(SK_CONV7, 7, a6, nullptr, a7, nullptr, Hp / 2, Wp / 2);
+        // (a caller that wants the intermediate maps gets the strip launches, which store them)
+        const bool pm1 = p.lpair[FK_M1] && !taps, pm2 = p.lpair[FK_M2] && !taps, pm3 = p.lpair[FK_M3] && !taps;
+        if (pm1) pair(FK_M1, 2, a4, nullptr, s2, a5, Hp / 2, Wp / 2);
+        else {
+            strip(SK_CONV2, 2, a4, nullptr, a2, nullptr, Hp / 2, Wp / 2);
+            strip(SK_CONV3, 3, a2, nullptr, s2, a5, Hp / 2, Wp / 2);
+        }
+        if (pm2) pair(FK_M2, 4, a5, nullptr, a4, nullptr, Hp / 4, Wp / 4);   // (conv5's map in a4 instead of a5)
+        else {
+            strip(SK_CONV4, 4, a5, nullptr, a4, nullptr, Hp / 4, Wp / 4);
+            strip(SK_CONV5, 5, a4, nullptr, a5, nullptr, Hp / 4, Wp / 4);
+        }
+        const void *c5 = pm2 ? a4 : a5;
+        if (pm3) pair(FK_M3, 6, c5, s2, a7, nullptr, Hp / 2, Wp / 2);
+        else {
+            strip(SK_CONV6, 6, c5, s2, a6, nullptr, Hp / 2, Wp / 2);
+            strip(SK_CONV7, 7, a6, nullptr, a7, nullptr, Hp / 2, Wp / 2);
+        }
         strip(SK_CONV8, 8, a7, s1, a8, nullptr, Hp, Wp);
         if (fuse_head) strip(SK_CONV9H2, 9, a8, nullptr, nullptr, nullptr, Hp, Wp);
         else strip(SK_CONV9S, 9, a8, nullptr, a9, nullptr, Hp, Wp);

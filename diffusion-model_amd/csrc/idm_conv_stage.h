@@ -71,6 +71,16 @@ DEVI float silu1(float z)
     return z * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+// silu of four values, one float at a time when PLAIN (translation units built with -fno-slp-vectorize, or the compiler
+// pairs the operations up again): a v_pk_*_f32 instruction waits while another wavefront of the SIMD streams MFMAs, which
+// costs epilogue-heavy layers more than the packed form's fewer instructions save.  Both forms give the same bits.
+template <bool PLAIN>
+DEVI f32x4 silu4t(f32x4 z)
+{
+    if constexpr (PLAIN) return f32x4{silu1(z[0]), silu1(z[1]), silu1(z[2]), silu1(z[3])};
+    else return silu4(z);
+}
+
 DEVI bf16x4 pack4(float a, float b, float c, float d)
 {
     bf16x4 o = {(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};

@@ -357,7 +357,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
                 char *dst = lds_mid + __mul24(__mul24(r, W + 2) + x + 1, SM) + (mt * 32 + 4 * h) * 2;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-#ifdef IDM_EPI_SCALAR
+                    // Epilogues run on the plain float32 ALU (this file is built with -fno-slp-vectorize so that the
+                    // compiler does not pair them up again): a v_pk_*_f32 instruction waits while another wavefront of
+                    // the SIMD streams MFMAs, and with three workgroups per CU one nearly always does.  Same bits as the
+                    // packed form (-DIDM_EPI_PACKED), which costs fused_A 4 %, fused_M1 5 % and fused_M2 2 %.
+#ifndef IDM_EPI_PACKED
                     float z[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
         if constexpr (EPI2 == E2_HEAD) {
             auto epi2 = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *kw, int mt, int r, int x, bool valid) {
                 (void)mt;
-#ifdef IDM_EPI_SCALAR
+#ifndef IDM_EPI_PACKED
                 float p4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
                 char *dst = stage + __mul24(__mul24(r, W) + x, SO) + (mt * 32 + 4 * h) * 2;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-#ifdef IDM_EPI_SCALAR
+#ifndef IDM_EPI_PACKED
                     float z[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) z[i] = silu1(BIAS_IN_ACC ? acc[4 * g + i] : acc[4 * g + i] + kb[g][i]);

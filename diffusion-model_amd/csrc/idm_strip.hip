@@ -94,6 +94,10 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
         cst[2 * COUT + 1] = EPI == SE_HEAD2 ? a.b_head[1] : 0.0f;
     }
 
+    // Layers with few input channels per output value spend most of their time in the epilogue: those run it on the
+    // plain float32 ALU (measured per layer at L = 64 / 128: conv2, conv3, conv7, conv9 4-6 % faster; conv4, conv5,
+    // conv6, conv8 3-4 % slower, so they keep the packed form).
+    constexpr bool PLAIN_EPI = CA + CB <= 64 && COUT <= 64;
     const LaneGeo geo = make_geo(WS, lane & 31);
     using Conv = ConvStage<CA, CB, UP, COUT, NT, MS, WD, TADD || EPI == SE_HEAD || EPI == SE_HEAD2>;
     Conv cs;
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                    p4 += silu4(BIAS_IN_ACC ? z : z + kb[g]) * kw[g];
+                    p4 += silu4t<PLAIN_EPI>(BIAS_IN_ACC ? z : z + kb[g]) * kw[g];
                 }
                 float part = (p4[0] + p4[1]) + (p4[2] + p4[3]);
                 part += __shfl_xor(part, 32, 64);
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                    z = silu4(BIAS_IN_ACC ? z : z + kb[g]);
+                    z = silu4t<PLAIN_EPI>(BIAS_IN_ACC ? z : z + kb[g]);
                     pa += z * kw[g];
                     pb += z * *(const f32x4 *)(c_3 + 8 * g + 4 * h);
                 }
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                    z = silu4(BIAS_IN_ACC ? z : z + kb[g]);
+                    z = silu4t<PLAIN_EPI>(BIAS_IN_ACC ? z : z + kb[g]);
                     if constexpr (TADD) z = z + kt[g];
                     *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
                 }

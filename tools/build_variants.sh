@@ -9,7 +9,7 @@ n=0
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
   n=$((n + 1)); [ $((n % 4)) -eq 0 ] && wait
-  ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -c idm_fused.hip -o /tmp/var_$name.o &&
+  ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize $flags -c idm_fused.hip -o /tmp/var_$name.o &&
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize $flags -c idm_fused_split.hip -o /tmp/var_${name}_split.o &&
     hipcc --offload-arch=gfx950 -shared -fPIC -o ../isingdiff/abl/lib_$name.so idm_api.o idm_canon.o idm_fast.o idm_strip.o idm_tileconv.o idm_bitflip.o idm_mlp.o idm_fft.o idm_comm.o idm_xy.o /tmp/var_$name.o /tmp/var_${name}_split.o || echo "FAILED $name" ) &
 done

@@ -286,7 +286,75 @@ __global__ __launch_bounds__(FWG, 1) void mlp_step_bf16_kernel(MlpFastArgs a)
             const int m0 = wave * 2;             // (host-checked: MT <= 16, one pair of cout tiles per wavefront at most)
             if (m0 < MT) compute(m0);
             __syncthreads();                     // every wavefront has read the layer's inputs
-            if (m0 < MT) epilogue(m0);
+            if (!last) {
+                if (m0 < MT) epilogue(m0);
+            } else {
+                // Last layer: an accumulator lane holds four outputs of ONE sample, so updating the state from the
+                // accumulators touches global memory in 32-byte pieces 4 n bytes apart.  The float32 scores cross LDS
+                // instead (the activation buffer is free now), 64 samples per round as [sample][n + 4], and the
+                // workgroup updates x a quad per thread, consecutive threads on consecutive quads of a row: coalesced
+                // reads and writes, one Philox call per quad with the counters of the float32 kernel.  Same expressions,
+                // hence the same bits, as the accumulator-side update of the 64-sample instance.
+                float *stage = (float *)smem;
+                const int sstr = a.n + 4, nq = a.n >> 2;
+                const int dS = FWG / nq, dQ = FWG - dS * nq;
+#pragma unroll
+                for (int r = 0; r < FNT / 2; ++r) {
+                    if (m0 < MT) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            if (t == 1 && m0 + 1 >= MT) break;
+#pragma unroll
+                            for (int qq = 0; qq < 2; ++qq) {
+                                const f32x16 &ac = acc[t][2 * r + qq];
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    const int c = (m0 + t) * 32 + 8 * g + 4 * h;
+                                    if (c < a.out_dim[l]) {
+                                        f32x4 z = {ac[4 * g], ac[4 * g + 1], ac[4 * g + 2], ac[4 * g + 3]};
+                                        z += *(const f32x4 *)(a.b[l] + c);
+                                        if (l == 0) z += *(const f32x4 *)(a.wt0 + c) * a.t_norm;
+                                        *(f32x4 *)(stage + (qq * 32 + nl) * sstr + c) = z;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    const int rows = min(64, ns - 64 * r);
+                    int sr = tid / nq, qd = tid - sr * nq;
+                    for (int idx = tid; idx < rows * nq; idx += FWG) {
+                        const f32x4 z = *(const f32x4 *)(stage + sr * sstr + 4 * qd);
+                        const int sn = 64 * r + sr;
+                        const int64_t e = (b0 + sn) * a.n + 4 * qd;
+                        if (a.score_out) *(f32x4 *)(a.score_out + e) = z;
+                        if (a.do_update) {
+                            f32x4 xv = *(const f32x4 *)(a.x + e);
+                            float zz[4] = {0.f, 0.f, 0.f, 0.f};
+                            if (a.add_noise) {
+                                if (a.noise) {
+                                    const f32x4 zv = *(const f32x4 *)(a.noise + e);
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) zz[i] = zv[i];
+                                } else {
+                                    normal4(a.ph.seed, a.ph.first_global_index + b0 + sn, (uint32_t)qd, a.ph.t, zz);
+                                }
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                float v = a.c1 * xv[i] + a.beta * z[i];
+                                if (a.add_noise) v += zz[i] * a.sd;
+                                xv[i] = v;
+                            }
+                            *(f32x4 *)(a.x + e) = xv;
+                        }
+                        sr += dS;
+                        qd += dQ;
+                        if (qd >= nq) { qd -= nq; ++sr; }
+                    }
+                    if (r + 1 < FNT / 2) __syncthreads();   // the staged scores are read before the next round overwrites them
+                }
+            }
         } else {
             for (int m0 = wave * 2; m0 < MT; m0 += 2 * (FWG / 64)) {
                 compute(m0);

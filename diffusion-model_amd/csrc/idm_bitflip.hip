@@ -161,8 +161,15 @@ __global__ __launch_bounds__(256) void bf_gn_apply_kernel(const float *__restric
 // channels, hence one group (a group is a multiple of four channels wide).  Mean, then variance of the centred values,
 // float32, partial sums folded per group through LDS; swish through the hardware exp2 / rcp.  Not the parity mode's
 // summation order: used only where the output is rounded to bf16.
+// The input of a ResBlock that follows an upsampling stage, x = Concatenate([UpSampling2D(up), skip]) (:225-226, :230-231),
+// read in place: up is (B, Hh, Wh, Cu), skip is (B, 2 Hh, 2 Wh, Cs).  up == nullptr: a plain tensor.
+struct UpCatSrc {
+    const float *up, *skip;
+    int Hh, Wh, Cu, Cs;
+};
+
 template <int THREADS, int NV>
-__global__ __launch_bounds__(THREADS) void bf_gn_fused_bf16_kernel(const float *__restrict__ x, int HW, int C,
+__global__ __launch_bounds__(THREADS) void bf_gn_fused_bf16_kernel(const float *__restrict__ x, UpCatSrc uc, int HW, int C,
                                                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                    __bf16 *__restrict__ y)
 {
@@ -171,12 +178,31 @@ __global__ __launch_bounds__(THREADS) void bf_gn_fused_bf16_kernel(const float *
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Q = C >> 2, Qg = Q >> 3, nq = HW * Q;          // quads per pixel, per group and pixel, per sample
     const int c4 = tid % Q, grp = c4 / Qg;
-    const float *xb = x + (size_t)blockIdx.x * HW * C;
     f32x4 v[NV];
+    if (uc.up) {
+        // a thread's quads are the same four channels of pixels p0, p0 + dp, ...: either all from up or all from skip
+        const int Wo = 2 * uc.Wh, dp = THREADS / Q, dy = dp / Wo, dx = dp - dy * Wo;
+        const int p0 = tid / Q;
+        int py = p0 / Wo, px = p0 - py * Wo;
+        const bool from_up = 4 * c4 < uc.Cu;
+        const float *ub = uc.up + (size_t)blockIdx.x * uc.Hh * uc.Wh * uc.Cu + 4 * c4;
+        const float *sb = uc.skip + (size_t)blockIdx.x * HW * uc.Cs + (4 * c4 - uc.Cu);
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const int q = tid + k * THREADS;
-        v[k] = q < nq ? *(const f32x4 *)(xb + (size_t)q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < NV; ++k) {
+            const int q = tid + k * THREADS;
+            const float *src = from_up ? ub + (size_t)((py >> 1) * uc.Wh + (px >> 1)) * uc.Cu : sb + (size_t)(py * Wo + px) * uc.Cs;
+            v[k] = q < nq ? *(const f32x4 *)src : f32x4{0.f, 0.f, 0.f, 0.f};
+            py += dy;
+            px += dx;
+            if (px >= Wo) { px -= Wo; ++py; }
+        }
+    } else {
+        const float *xb = x + (size_t)blockIdx.x * HW * C;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int q = tid + k * THREADS;
+            v[k] = q < nq ? *(const f32x4 *)(xb + (size_t)q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
     // sum over the threads of each group: wavefront w folds groups w, w + waves, ...; entry e of group g is thread
     // (e / Qg) * Q + g * Qg + e % Qg
@@ -238,21 +264,25 @@ __global__ __launch_bounds__(THREADS) void bf_gn_fused_bf16_kernel(const float *
 // Launches the fused kernel when a (threads, quads per thread) instance covers the sample; false: the caller takes the
 // two-kernel path.
 template <int THREADS, int NV>
-bool gn_fused_try(const float *x, int64_t B, int HW, int C, const float *gamma, const float *beta, __bf16 *y, hipStream_t s)
+bool gn_fused_try(const float *x, const UpCatSrc &uc, int64_t B, int HW, int C, const float *gamma, const float *beta, __bf16 *y,
+                  hipStream_t s, bool probe)
 {
     const int Q = C / 4;
     if (THREADS % Q != 0 || (int64_t)HW * Q > (int64_t)THREADS * NV) return false;
-    hipLaunchKernelGGL((bf_gn_fused_bf16_kernel<THREADS, NV>), dim3((unsigned)B), dim3(THREADS), 0, s, x, HW, C, gamma, beta, y);
+    if (!probe)
+        hipLaunchKernelGGL((bf_gn_fused_bf16_kernel<THREADS, NV>), dim3((unsigned)B), dim3(THREADS), 0, s, x, uc, HW, C, gamma, beta, y);
     return true;
 }
 
-bool gn_fused_bf16(const float *x, int64_t B, int HW, int C, const float *gamma, const float *beta, __bf16 *y, hipStream_t s)
+// probe: only tell whether an instance covers the sample
+bool gn_fused_bf16(const float *x, const UpCatSrc &uc, int64_t B, int HW, int C, const float *gamma, const float *beta, __bf16 *y,
+                   hipStream_t s, bool probe = false)
 {
     if (C % 32 != 0 || B > 0x7fffffff) return false;   // eight groups of a multiple of four channels
-    return gn_fused_try<256, 4>(x, B, HW, C, gamma, beta, y, s) || gn_fused_try<256, 8>(x, B, HW, C, gamma, beta, y, s) ||
-           gn_fused_try<256, 16>(x, B, HW, C, gamma, beta, y, s) || gn_fused_try<256, 28>(x, B, HW, C, gamma, beta, y, s) ||
-           gn_fused_try<768, 4>(x, B, HW, C, gamma, beta, y, s) || gn_fused_try<768, 13>(x, B, HW, C, gamma, beta, y, s) ||
-           gn_fused_try<768, 25>(x, B, HW, C, gamma, beta, y, s) || gn_fused_try<1024, 20>(x, B, HW, C, gamma, beta, y, s);
+    return gn_fused_try<256, 4>(x, uc, B, HW, C, gamma, beta, y, s, probe) || gn_fused_try<256, 8>(x, uc, B, HW, C, gamma, beta, y, s, probe) ||
+           gn_fused_try<256, 16>(x, uc, B, HW, C, gamma, beta, y, s, probe) || gn_fused_try<256, 28>(x, uc, B, HW, C, gamma, beta, y, s, probe) ||
+           gn_fused_try<768, 4>(x, uc, B, HW, C, gamma, beta, y, s, probe) || gn_fused_try<768, 13>(x, uc, B, HW, C, gamma, beta, y, s, probe) ||
+           gn_fused_try<768, 25>(x, uc, B, HW, C, gamma, beta, y, s, probe) || gn_fused_try<1024, 20>(x, uc, B, HW, C, gamma, beta, y, s, probe);
 }
 
 // out = (conv1x1(x) + bias) + h  (the ResBlock's projected shortcut, :188-192); w == nullptr: out = x + h.
@@ -278,9 +308,9 @@ __global__ __launch_bounds__(256) void bf_shortcut_kernel(const float *__restric
 // on the way into the MFMA; wpack: bf16 A fragments [c / 16][Cout / 32][lane][8] (the centre tap of the 3x3 packing).
 // HBM-bound: x, h in and out out once each.
 template <int MT>
-__global__ __launch_bounds__(256) void bf_shortcut_mfma_kernel(const float *__restrict__ x, int Cin, const bf16x8 *__restrict__ wpack,
-                                                               const float *__restrict__ bias, const float *__restrict__ hres,
-                                                               float *__restrict__ out, int64_t npix)
+__global__ __launch_bounds__(256) void bf_shortcut_mfma_kernel(const float *__restrict__ x, UpCatSrc uc, int Cin,
+                                                               const bf16x8 *__restrict__ wpack, const float *__restrict__ bias,
+                                                               const float *__restrict__ hres, float *__restrict__ out, int64_t npix)
 {
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -288,6 +318,17 @@ __global__ __launch_bounds__(256) void bf_shortcut_mfma_kernel(const float *__re
     const int64_t p = tile * 32 + li;
     const bool pv = p < npix;
     const float *xp = x + (pv ? p : 0) * Cin + 8 * h;
+    // upsample-concat input (Cu a multiple of 16): channel groups below Cu come from up's pixel (y / 2, x / 2), the others
+    // from skip; xs is biased so that xs + c is skip's channel c - Cu
+    const float *xu = nullptr, *xs = nullptr;
+    if (uc.up) {
+        const int64_t pp = pv ? p : 0;
+        const int Wo = 2 * uc.Wh, HWo = 4 * uc.Hh * uc.Wh;
+        const int64_t b = pp / HWo;
+        const int r = (int)(pp - b * HWo), py = r / Wo, px = r - py * Wo;
+        xu = uc.up + ((b * uc.Hh + (py >> 1)) * uc.Wh + (px >> 1)) * uc.Cu + 8 * h;
+        xs = uc.skip + pp * uc.Cs - uc.Cu + 8 * h;
+    }
     f32x16 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -295,7 +336,8 @@ __global__ __launch_bounds__(256) void bf_shortcut_mfma_kernel(const float *__re
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
     const int ncg = Cin >> 4;
     for (int cg = 0; cg < ncg; ++cg) {
-        const f32x4 v0 = *(const f32x4 *)(xp + 16 * cg), v1 = *(const f32x4 *)(xp + 16 * cg + 4);
+        const float *src = !uc.up ? xp + 16 * cg : (16 * cg < uc.Cu ? xu : xs) + 16 * cg;
+        const f32x4 v0 = *(const f32x4 *)src, v1 = *(const f32x4 *)(src + 4);
         const bf16x8 bv = {(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3],
                            (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
 #pragma unroll
@@ -485,9 +527,9 @@ int time_vectors(idm_bitflip *m, const float *emb_host, int rows, hipStream_t s)
 
 // y: float32, or bf16 in the same buffer when `half`
 void gn_silu(const float *x, int64_t B, int HW, int C, const float *gamma, const float *beta, float *ab, float *y, bool half,
-             hipStream_t s)
+             hipStream_t s, const UpCatSrc &uc = UpCatSrc{})
 {
-    if (half && gn_fused_bf16(x, B, HW, C, gamma, beta, (__bf16 *)y, s)) return;
+    if (half && gn_fused_bf16(x, uc, B, HW, C, gamma, beta, (__bf16 *)y, s)) return;
     hipLaunchKernelGGL(bf_gn_stats_kernel, dim3((unsigned)((B * 8 + 3) / 4)), dim3(256), 0, s, x, B, HW, C, gamma, beta, ab);
     const int64_t n = B * HW * C;
     if (half)
@@ -497,37 +539,63 @@ void gn_silu(const float *x, int64_t B, int HW, int C, const float *gamma, const
 }
 
 // half: `in` holds bf16 and wpack bf16 fragments -> bf16 MFMA kernel (float32 accumulation and output)
-void conv3(const float *in, int64_t B, int H, int W, int Cin, const void *wpack, const float *bias, const float *tadd,
-           float *out, int Cout, bool half, hipStream_t s)
+// resid / res_out (bf16 mode only, may be null): when the LDS-tiled kernel covers the shape it writes
+// res_out = (conv + bias) + resid instead of out and the function returns true (the block's identity shortcut rides in the
+// convolution's epilogue); false: out holds the plain convolution.
+bool conv3(const float *in, int64_t B, int H, int W, int Cin, const void *wpack, const float *bias, const float *tadd,
+           float *out, int Cout, bool half, hipStream_t s, const float *resid = nullptr, float *res_out = nullptr)
 {
     ConvArgs a = {};
     a.in0 = in; a.in1 = nullptr; a.C0 = Cin; a.C1 = 0; a.H = H; a.W = W; a.B = B; a.wpack = wpack; a.bias = bias;
     a.scale = nullptr; a.shift = nullptr; a.tadd = tadd; a.out = out; a.Cout = Cout; a.mode = CONV_PLAIN; a.silu = 0;
     a.out_f32 = 1;
-    if (!half) launch_conv_f32(a, s);
-    else if (!launch_conv_tile_bf16(a, s)) launch_conv_bf16(a, s);   // (wider maps and other channel counts: per-layer kernel)
+    if (!half) { launch_conv_f32(a, s); return false; }
+    if (resid && res_out) {
+        a.resid = resid; a.out = res_out;
+        if (launch_conv_tile_bf16(a, s)) return true;
+        a.resid = nullptr; a.out = out;
+    }
+    if (!launch_conv_tile_bf16(a, s)) launch_conv_bf16(a, s);   // (wider maps and other channel counts: per-layer kernel)
+    return false;
 }
 
 // ResBlock (:168-193).  ta: >= B*H*W*max(Cin,width) floats, tbuf: >= B*H*W*width floats.
-void resblock(idm_bitflip *m, int i, const float *x, int64_t B, int H, int W, const float *tvec, float *out, float *ta,
-              float *tbuf, float *ab, hipStream_t s)
+// cat (optional): x = Concatenate([UpSampling2D(cat->up), cat->skip]).  In the bf16 mode the block's two readers of x (the
+// first GroupNorm and the projected shortcut) read the two tensors in place when their fused kernels cover the shape;
+// otherwise the concatenation is first written to x.
+void resblock(idm_bitflip *m, int i, float *x, int64_t B, int H, int W, const float *tvec, float *out, float *ta,
+              float *tbuf, float *ab, hipStream_t s, const UpCatSrc *cat = nullptr)
 {
     const int Cin = kCin[i], Cw = kWidth[i], HW = H * W;
     const bool half = m->precision == IDM_BF16;
-    gn_silu(x, B, HW, Cin, m->t[tb(i, K_G1_G)], m->t[tb(i, K_G1_B)], ab, ta, half, s);
+    const bool mfma_shortcut = half && m->s_pack16[i] && Cw % 32 == 0 && Cw <= 128 && Cin % 16 == 0;
+    UpCatSrc uc = {};
+    if (cat) {
+        const bool in_place = mfma_shortcut && cat->Cu % 16 == 0 && cat->Cs % 4 == 0 &&
+                              gn_fused_bf16(nullptr, *cat, B, HW, Cin, nullptr, nullptr, nullptr, s, true);
+        if (in_place) uc = *cat;
+        else
+            hipLaunchKernelGGL(bf_upcat_kernel, dim3(blocks(B * HW * Cin / 4)), dim3(256), 0, s, cat->up, cat->skip, x, B, cat->Hh,
+                               cat->Wh, cat->Cu, cat->Cs);
+    }
+    gn_silu(x, B, HW, Cin, m->t[tb(i, K_G1_G)], m->t[tb(i, K_G1_B)], ab, ta, half, s, uc);
     conv3(ta, B, H, W, Cin, half ? m->c1_pack16[i] : m->c1_pack[i], m->t[tb(i, K_C1_B)], tvec, tbuf, Cw, half, s);
     gn_silu(tbuf, B, HW, Cw, m->t[tb(i, K_G2_G)], m->t[tb(i, K_G2_B)], ab, ta, half, s);
-    conv3(ta, B, H, W, Cw, half ? m->c2_pack16[i] : m->c2_pack[i], m->t[tb(i, K_C2_B)], nullptr, tbuf, Cw, half, s);
+    // identity shortcut (Cin == width, :188-192 take the other branch): out = x + h, in the bf16 mode inside the convolution
+    const bool identity = !m->s_pack[i] && !(half && m->s_pack16[i]);
+    if (conv3(ta, B, H, W, Cw, half ? m->c2_pack16[i] : m->c2_pack[i], m->t[tb(i, K_C2_B)], nullptr, tbuf, Cw, half, s,
+              half && identity ? x : nullptr, out))
+        return;
     const int64_t npix = B * HW;
-    if (half && m->s_pack16[i] && Cw % 32 == 0 && Cw <= 128 && Cin % 16 == 0) {
+    if (mfma_shortcut) {
         const unsigned grid = (unsigned)((npix + 127) / 128);
         const bf16x8 *wp = (const bf16x8 *)m->s_pack16[i];
         const float *sb = m->t[tb(i, K_S_B)];
         switch (Cw / 32) {
-        case 1: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<1>, dim3(grid), dim3(256), 0, s, x, Cin, wp, sb, (const float *)tbuf, out, npix); break;
-        case 2: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<2>, dim3(grid), dim3(256), 0, s, x, Cin, wp, sb, (const float *)tbuf, out, npix); break;
-        case 3: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<3>, dim3(grid), dim3(256), 0, s, x, Cin, wp, sb, (const float *)tbuf, out, npix); break;
-        default: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<4>, dim3(grid), dim3(256), 0, s, x, Cin, wp, sb, (const float *)tbuf, out, npix); break;
+        case 1: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<1>, dim3(grid), dim3(256), 0, s, (const float *)x, uc, Cin, wp, sb, (const float *)tbuf, out, npix); break;
+        case 2: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<2>, dim3(grid), dim3(256), 0, s, (const float *)x, uc, Cin, wp, sb, (const float *)tbuf, out, npix); break;
+        case 3: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<3>, dim3(grid), dim3(256), 0, s, (const float *)x, uc, Cin, wp, sb, (const float *)tbuf, out, npix); break;
+        default: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<4>, dim3(grid), dim3(256), 0, s, (const float *)x, uc, Cin, wp, sb, (const float *)tbuf, out, npix); break;
         }
     } else if (m->s_pack[i]) {
         // projected shortcut (:188-192) on the matrix cores: the centre tap alone is a 1x1 convolution with the
@@ -564,12 +632,9 @@ int forward_chunk(idm_bitflip *m, const uint8_t *x, const float *tvec, float *pr
     resblock(m, 1, pl, Bc, H2, W2, tv[1], r1, ta, tbuf, ab, s);
     hipLaunchKernelGGL(bf_maxpool_kernel, dim3(blocks(Bc * hw * 4)), dim3(256), 0, s, (const float *)r1, pl, Bc, H2, W2, 64);
     resblock(m, 2, pl, Bc, H4, W4, tv[2], r2, ta, tbuf, ab, s);
-    hipLaunchKernelGGL(bf_upcat_kernel, dim3(blocks(Bc * hw * 48 / 4)), dim3(256), 0, s, (const float *)r2, (const float *)r1,
-                       cat, Bc, H4, W4, 128, 64);
-    resblock(m, 3, cat, Bc, H2, W2, tv[3], d3, ta, tbuf, ab, s);
-    hipLaunchKernelGGL(bf_upcat_kernel, dim3(blocks(Bc * hw * 96 / 4)), dim3(256), 0, s, (const float *)d3, (const float *)r0,
-                       cat, Bc, H2, W2, 64, 32);
-    resblock(m, 4, cat, Bc, H, W, tv[4], d4, ta, tbuf, ab, s);
+    const UpCatSrc cat3 = {r2, r1, H4, W4, 128, 64}, cat4 = {d3, r0, H2, W2, 64, 32};
+    resblock(m, 3, cat, Bc, H2, W2, tv[3], d3, ta, tbuf, ab, s, &cat3);
+    resblock(m, 4, cat, Bc, H, W, tv[4], d4, ta, tbuf, ab, s, &cat4);
     hipLaunchKernelGGL(bf_head_kernel, dim3(blocks(Bc * hw)), dim3(256), 0, s, (const float *)d4, m->t[T_OUT_W],
                        m->t[T_OUT_B], proba, (int64_t)(Bc * hw));
     if (taps) {

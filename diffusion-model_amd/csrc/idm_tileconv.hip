@@ -15,7 +15,8 @@ namespace {
 template <int CA, int COUT, int NT, int MS, int WD, int NP>
 __global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__restrict__ in, const bf16x8 *__restrict__ w,
                                                               const float *__restrict__ bias, const float *__restrict__ tadd,
-                                                              float *__restrict__ out, int H, int W, int R, int nbands)
+                                                              const float *__restrict__ resid, float *__restrict__ out, int H,
+                                                              int W, int R, int nbands)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SA = CA * 2 + 16;
@@ -38,13 +39,17 @@ __global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__r
     cs.begin(tile, nullptr, cst, cst + COUT, geo, 0, rows, w, wave, lane);
     __syncthreads();
     float *ob = out + ((size_t)b * H + y0) * W * COUT;
+    // resid (same shape as out, may be null): added last, out = (conv + bias + vector) + resid - a ResBlock's identity shortcut
+    const float *rb = resid ? resid + ((size_t)b * H + y0) * W * COUT : nullptr;
     cs.run([&](const f32x16 &acc, const f32x4 *, const f32x4 *kt, int mt, int r, int x, bool valid) {
         if (!valid) return;
-        float *dst = ob + ((size_t)r * W + x) * COUT + mt * 32 + 4 * h;
+        const size_t o = ((size_t)r * W + x) * COUT + mt * 32 + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-            *(f32x4 *)(dst + 8 * g) = z + kt[g];
+            f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            z = z + kt[g];
+            if (rb) z = z + *(const f32x4 *)(rb + o + 8 * g);
+            *(f32x4 *)(ob + o + 8 * g) = z;
         }
     });
 }
@@ -76,7 +81,7 @@ bool launch_tile(const ConvArgs &a, hipStream_t s)
         configured[slot] = true;
     }
     hipLaunchKernelGGL(kernel, dim3((unsigned)(a.B * nb)), dim3(256), lds, s, (const __bf16 *)a.in0, (const bf16x8 *)a.wpack, a.bias,
-                       a.tadd, (float *)a.out, a.H, a.W, R, nb);
+                       a.tadd, a.resid, (float *)a.out, a.H, a.W, R, nb);
     return true;
 }
 

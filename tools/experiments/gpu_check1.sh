@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 first GPU check: allocation-free entry point, FFT kernel variants, full GPU suite, short bench.
+# One-call GPU check: allocation-free entry point, FFT kernel variants, full GPU suite, short bench.
 set -o pipefail
 mkdir -p gpurun_out/r2
 timeout -k 10 300 python -u -m pytest tests/wip_no_alloc.py -x -q --timeout 120 --timeout-method thread > gpurun_out/r2/noalloc.log 2>&1; rc=$?

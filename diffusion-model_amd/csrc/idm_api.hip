@@ -248,6 +248,9 @@ Plan make_plan(const idm_model *m, int H, int W, int precision)
             p.strip[k] = ok && (p.R[k] < below && p.R[k] < hh[k]);
             if (p.R[k] == 0 && !p.strip[k]) p.fused = false;
         }
+        // conv2 + conv3 of the 32 x 32 lattice: the instance that takes the whole 16 x 16 map
+        if (p.fused && !p.strip[FK_M1] && p.H == p.Hp && p.W == p.Wp)
+            if (const int r = fused_m1_whole_rows(p.H, p.W)) p.R[FK_M1] = r;
     }
     p.layers = false;
     if (precision == IDM_BF16 && !p.fused && m->use_fused && (m->C == 2 || m->bn)) {

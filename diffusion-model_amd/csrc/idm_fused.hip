@@ -22,6 +22,11 @@
 //     and the next band's clears are ordered by the next B1.
 // Moving a clear ahead of B1, or the carry copy ahead of B3, is a race that shows only as rare wrong bits; the
 // batch-composition property test (a lattice's result does not depend on which workgroup ran it) guards it.
+// The conv2 + conv3 instance on the whole 16 x 16 map (ALIAS in the kernel) keeps its staging tile OVER the mid tile:
+//  B2' between conv2's MFMA loop and its epilogue - every wavefront has issued its last MFMA on the mid tile before any
+//     writes the staging tile (each wavefront runs exactly one piece, so all reach it once);
+//  B4 then also orders the copy-out's reads of the staging tile before the next lattice's conv1 epilogue writes the mid
+//     tile, whose halo columns and padding rows are cleared again after B1 (the staged output lay over them).
 //
 // The UNet's data movement is folded into the edges:
 //     FIRST   conv1 reads the float32 state x (Cin = 1, the 9 taps are the K of one MFMA step,
@@ -158,6 +163,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
     constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16, SM = C1 * 2 + 16, SO = C2 * 2 + 16;
     constexpr int CAT = MODE1 == M1_FIRST ? 8 : CA, CBT = MODE1 == M1_UPCAT ? CB : 8;
     (void)SA; (void)SB; (void)SO;
+    // The conv2 + conv3 instance on the whole 16 x 16 map (one piece of four tiles per wavefront and convolution: every
+    // weight fragment feeds four MFMAs, half the weight stream of 8-row bands).  Two workgroups fit a CU only if the
+    // output staging tile lies OVER the mid tile, so conv3's epilogue waits (one more barrier) until every wavefront has
+    // issued its last MFMA on the mid tile, and the mid tile's zero halo is restored for every lattice.
+    constexpr bool ALIAS = MODE1 == M1_PLAIN && EPI2 == E2_STORE_POOL && CA == 32 && WT == 16 && RT == 16;
     // A workgroup owns whole lattices (blockIdx.x, blockIdx.x + gridDim.x, ...) and walks each one's bands top
     // to bottom: item n of a workgroup is band n % nbands of its (n / nbands)-th lattice.  The two bottom rows of
     // the mid tile (conv1 at global rows y0+R-1, y0+R) are what the next band needs as its rows 0 and 1, so they
@@ -346,6 +356,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
         // only rows inside the map, and conv2 reads after the next barrier.
         if (y0 == 0) clear_halo<C1, WGS>(lds_mid, W, 0, 0, 1, tid);
         if (rhi < R + 2) clear_halo<C1, WGS>(lds_mid, W, 0, rhi, R + 2, tid);
+        if constexpr (ALIAS) clear_halo<C1, WGS>(lds_mid, W, R + 2, 0, 0, tid);   // the previous lattice's staged output lay here
 
         // ---- conv1 on rows y0-1 .. y0+R (clipped to the map) -> mid tile row (g - (y0-1)) ----
         {
@@ -505,7 +516,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
                 }
             }
         } else {
-            char *stage = lds_in;  // [rows2][W] positions of SO bytes
+            char *stage = ALIAS ? lds_mid : lds_in;  // [rows2][W] positions of SO bytes
             auto epi2 = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *, int mt, int r, int x, bool valid) {
                 if (!valid) return;
                 char *dst = stage + __mul24(__mul24(r, W) + x, SO) + (mt * 32 + 4 * h) * 2;
@@ -522,7 +533,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
                     *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
                 }
             };
-            cs2.run(epi2, TLHOOK(18));
+            // (ALIAS: every wavefront runs exactly one piece here, so the barrier between its MFMA loop and its epilogue
+            // is reached once by all: no wavefront writes the staging tile while another still reads the mid tile under it)
+            if constexpr (ALIAS) cs2.run(epi2, [&](int i) { if (i == 1) __syncthreads(); });
+            else cs2.run(epi2, TLHOOK(18));
             TL(5);
             conv1_begin(nxt);
             if constexpr (!EARLY_PF) pf_load(nxt);
@@ -634,6 +648,15 @@ void fused_lds_bytes(int kind, int W, int R, int *in_bytes, int *mid_bytes)
     *mid_bytes = align16((R + 2) * (W + 2) * sm) + (2 * k.c1 + 2 * k.c2 + 4) * 4 + (k.epi2 == E2_HEAD ? align16(R * W * 4) : 0);
 }
 
+// conv2 + conv3 of the 32 x 32 lattice run on the whole 16 x 16 map (IDM_M1_WHOLE=0 at build time: 8-row bands).
+#ifndef IDM_M1_WHOLE
+#define IDM_M1_WHOLE 1
+#endif
+int fused_m1_whole_rows(int Hx, int Wx)
+{
+    return IDM_M1_WHOLE && Hx == 32 && Wx == 32 ? 16 : 0;
+}
+
 // Launch state per kernel instance (all instances share one function-pointer type, so the
 // state cannot live in a function-local static of the launcher template).
 struct LaunchState {
@@ -679,6 +702,9 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
 #ifndef IDM_CFG_M1
 #define IDM_CFG_M1 3, 1, 1, 2, 1, 1, 5, 0, 2
 #endif
+#ifndef IDM_CFG_M1W   // the whole-map instance: one four-tile piece per wavefront and convolution
+#define IDM_CFG_M1W 4, 1, 3, 4, 1, 3, 5, 0, 2
+#endif
 #ifndef IDM_CFG_M2
 #define IDM_CFG_M2 2, 1, 2, 2, 1, 2, 3, 0, 2
 #endif
@@ -702,6 +728,12 @@ hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
     // instances specialised for the L = 32 pyramid (widths 32 / 16 / 8; 8-row bands, M3 the whole 16-row map; no padding)
     const int w32[5] = {32, 16, 8, 16, 32}, r32[5] = {8, 8, 8, 16, IDM_B_WAVES == 8 ? 16 : 8};
     const bool spec = a.W == w32[kind] && a.R == r32[kind] && a.Hx == 32 && a.Wx == 32;
+    if (kind == FK_M1 && a.W == 16 && a.H == 16 && a.R == 16 && fused_m1_whole_rows(a.Hx, a.Wx) == 16) {
+        // whole-map instance: the staging tile lies over the mid tile, so the input region holds the input tile only
+        FusedArgs b = a;
+        b.lds_in_bytes = align16((16 + 4) * (16 + 2) * (32 * 2 + 16));
+        return launch_one(st[6], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1W, 16, 16>, b, B, s);
+    }
     if (spec) {
         switch (kind) {
         case FK_A: return launch_one(st[5], fused2_kernel<M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, false, IDM_CFG_A, 32, 8>, a, B, s);

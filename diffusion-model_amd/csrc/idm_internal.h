@@ -127,6 +127,7 @@ struct FusedArgs {
 void fused_lds_bytes(int kind, int W, int R, int *in_bytes, int *mid_bytes);
 bool fused_band_fits(int kind, int W, int R);
 int fused_tall_rows(int kind, int H, int W);
+int fused_m1_whole_rows(int Hx, int Wx);   // band rows of conv2 + conv3 when its whole-map instance applies, else 0
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s);
 // fused_B for the L = 32 lattice, MFMA and non-MFMA work on separate wavefronts (idm_fused_split.hip)
 hipError_t launch_b_split(const FusedArgs &a, int64_t B, hipStream_t s);

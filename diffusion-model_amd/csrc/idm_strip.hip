@@ -64,7 +64,8 @@ struct WinRegs {
 // their halo columns in L2.  Ordering of vector-memory traffic as in the fused kernels: the next
 // item's first weights are requested before its input, and both before the copy-out.
 // WST, RT: strip width and band rows as compile-time constants (0 = taken from the arguments).
-template <int CA, int CB, bool UP, int COUT, int EPI, bool TADD, int NT, int MS, int WD, int NPA, int NPB, int OCC, int WST, int RT>
+template <int CA, int CB, bool UP, int COUT, int EPI, bool TADD, int NT, int MS, int WD, int NPA, int NPB, int OCC, int WST, int RT,
+          bool ALIAS = false>
 __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,10 +77,16 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
     // work items are indexed in 32 bits (checked on the host)
     const int per_lat = a.nbands * a.nstrips, total = (int)a.B * per_lat;
 
+    // ALIAS: instances whose band is twice as tall as its LDS would otherwise allow (the host's table of tall instances):
+    // every wavefront runs ONE four-tile piece per work item, so a weight fragment feeds four MFMAs instead of two and
+    // fewer halo rows are re-read.  The output staging tile lies OVER the input windows; the epilogue therefore waits at a
+    // barrier until every wavefront has issued its last MFMA (each runs exactly one piece, so all reach that barrier
+    // once per item).
+    static_assert(!ALIAS || (WST == 32 && RT > 0 && NT == 4 && (EPI == SE_STORE || EPI == SE_STORE_POOL)), "aliased staging: store kernels with one piece per wavefront");
     // LDS map: [window a | window b | output staging | epilogue constants]
     char *tile_a = smem;
     char *tile_b = UP ? smem + ((((R >> 1) + 2) * ((WS >> 1) + 2) * SA + 15) & ~15) : nullptr;
-    char *stage = smem + a.lds_in_bytes;
+    char *stage = ALIAS ? smem : smem + a.lds_in_bytes;
     // constants: bias | second per-channel array (head weights / time add) | head bias (4 floats) | second head vector
     float *cst = (float *)(smem + a.lds_in_bytes + a.lds_stage_bytes);
     const float *c_b = cst, *c_2 = cst + COUT, *c_bh = cst + 2 * COUT, *c_3 = cst + 2 * COUT + 4;
@@ -272,7 +279,8 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
                     *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
                 }
             };
-            cs.run(epi);
+            if constexpr (ALIAS) cs.run(epi, [&](int i) { if (i == 1) __syncthreads(); });
+            else cs.run(epi);
             conv_begin(wg_next);
             pf_load(wg_next);
             __syncthreads();
@@ -327,6 +335,26 @@ constexpr StripKind kStrip[SK_COUNT] = {
 
 inline int a16(int v) { return (v + 15) & ~15; }
 
+// Tall instances for 32-column strips: a band of `rows` rows in which every wavefront runs one four-tile piece (16 work
+// units), with more prefetch registers (npa / npb) and, where the taller windows leave no room for it, the staging tile
+// over the input windows (alias).
+struct TallKind { int rows; bool alias; int npa, npb; };
+constexpr TallKind kTall[SK_COUNT] = {
+    {0, false, 0, 0},      // SK_CONV1
+    {0, false, 0, 0},      // SK_CONV2 (8 rows are 16 units already)
+    {8, true, 11, 0},      // SK_CONV3
+    {0, false, 0, 0},      // SK_CONV4 (4 rows are 16 units already)
+    {4, true, 13, 0},      // SK_CONV5
+    {0, false, 0, 0},      // SK_CONV6 (8 rows of its windows exceed the LDS of two workgroups per CU)
+    {8, true, 11, 0},      // SK_CONV7
+    {16, true, 6, 10},     // SK_CONV8
+    {16, false, 10, 0},    // SK_CONV9 (its staging tile is the small score tile)
+    {0, false, 0, 0},      // SK_CONV9S
+    {0, false, 0, 0},      // SK_CONV9H2
+};
+inline bool is_tall(int kind, int R, int WS) { return WS == 32 && R > 0 && R == kTall[kind].rows; }
+inline bool is_alias(int kind, int R, int WS) { return is_tall(kind, R, WS) && kTall[kind].alias; }
+
 struct StripLaunch {
     bool configured = false;
     int cus = 0, cached_lds = -1, cached_blocks = 0;
@@ -372,14 +400,23 @@ void strip_lds_bytes(int kind, int R, int WS, int *in_bytes, int *stage_bytes, i
     *in_bytes = a16(in);
     *stage_bytes = a16(k.epi == SE_HEAD ? R * WS * 4 : k.epi == SE_HEAD2 ? R * WS * 8 : R * WS * so);
     *const_bytes = (3 * k.cout + 4) * 4;
+    if (is_alias(kind, R, WS)) {   // the staging tile shares the windows' bytes
+        *in_bytes = *in_bytes > *stage_bytes ? *in_bytes : *stage_bytes;
+        *stage_bytes = 0;
+    }
 }
 
 // True when the next item's windows fit the instance's prefetch registers.
 bool strip_fits(int kind, int R, int WS)
 {
     const StripKind &k = kStrip[kind];
-    if (!k.up) return (R + 2) * (WS + 2) * (k.ca / 8) <= k.npa * WG;
-    return (R / 2 + 2) * (WS / 2 + 2) * (k.ca / 8) <= k.npa * WG && (R + 2) * (WS + 2) * (k.cb / 8) <= k.npb * WG;
+    int npa = k.npa, npb = k.npb;
+    if (is_tall(kind, R, WS)) {
+        npa = kTall[kind].npa;
+        npb = kTall[kind].npb;
+    }
+    if (!k.up) return (R + 2) * (WS + 2) * (k.ca / 8) <= npa * WG;
+    return (R / 2 + 2) * (WS / 2 + 2) * (k.ca / 8) <= npa * WG && (R + 2) * (WS + 2) * (k.cb / 8) <= npb * WG;
 }
 
 #define STRIP_INST(idx, R8, ...)                                                                          \
@@ -393,16 +430,26 @@ bool strip_fits(int kind, int R, int WS)
 
 hipError_t launch_strip(int kind, const StripArgs &a, hipStream_t s)
 {
-    static thread_local StripLaunch all_st[IDM_MAX_DEVICES][2 * SK_COUNT];
+    static thread_local StripLaunch all_st[IDM_MAX_DEVICES][2 * SK_COUNT + 5];
     const int slot = idm_device_slot();
     if (slot < 0) return hipErrorInvalidDevice;
     StripLaunch *st = all_st[slot];
+    if (is_tall(kind, a.R, a.WS)) {
+        constexpr int T = 2 * SK_COUNT;
+        switch (kind) {
+        case SK_CONV3: return launch_strip_one(st[T + 0], strip_kernel<64, 0, false, 64, SE_STORE_POOL, false, 4, 1, IDM_STRIP_WD, kTall[SK_CONV3].npa, 0, 2, 32, 8, true>, a, s);
+        case SK_CONV5: return launch_strip_one(st[T + 1], strip_kernel<128, 0, false, 128, SE_STORE, false, 4, 1, IDM_STRIP_WD, kTall[SK_CONV5].npa, 0, 2, 32, 4, true>, a, s);
+        case SK_CONV7: return launch_strip_one(st[T + 2], strip_kernel<64, 0, false, 64, SE_STORE, false, 4, 1, IDM_STRIP_WD, kTall[SK_CONV7].npa, 0, 2, 32, 8, true>, a, s);
+        case SK_CONV8: return launch_strip_one(st[T + 3], strip_kernel<64, 32, true, 32, SE_STORE, false, 4, 1, IDM_STRIP_WD, kTall[SK_CONV8].npa, kTall[SK_CONV8].npb, 2, 32, 16, true>, a, s);
+        default: return launch_strip_one(st[T + 4], strip_kernel<32, 0, false, 32, SE_HEAD, false, 4, 1, IDM_STRIP_WD, kTall[SK_CONV9].npa, 0, 2, 32, 16>, a, s);
+        }
+    }
     // second argument: the band height make_plan picks for 32-column strips (specialised instance)
     switch (kind) {
     case SK_CONV1: return STRIP_INST(0, 8, 32, 0, false, 32, SE_STORE_POOL, false, 3, 1, IDM_STRIP_WD, 6, 0, 2);
-    case SK_CONV2: return STRIP_INST(1, 8, 32, 0, false, 64, SE_STORE, false, 3, 1, IDM_STRIP_WD, 6, 0, 2);
+    case SK_CONV2: return STRIP_INST(1, 8, 32, 0, false, 64, SE_STORE, false, 4, 1, IDM_STRIP_WD, 6, 0, 2);   // (8 rows x 2 cout slices: one four-tile piece per wavefront)
     case SK_CONV3: return STRIP_INST(2, 4, 64, 0, false, 64, SE_STORE_POOL, false, 3, 1, IDM_STRIP_WD, 11, 0, 2);
-    case SK_CONV4: return STRIP_INST(3, 4, 64, 0, false, 128, SE_STORE, true, 3, 1, IDM_STRIP_WD, 11, 0, 2);
+    case SK_CONV4: return STRIP_INST(3, 4, 64, 0, false, 128, SE_STORE, true, 4, 1, IDM_STRIP_WD, 11, 0, 2);   // (4 rows x 4 cout slices: likewise)
     case SK_CONV5: return STRIP_INST(4, 2, 128, 0, false, 128, SE_STORE, false, 3, 1, IDM_STRIP_WD, 11, 0, 2);
     case SK_CONV6: return STRIP_INST(5, 4, 128, 64, true, 64, SE_STORE, false, 3, 1, IDM_STRIP_WD, 7, 11, 2);
     case SK_CONV7: return STRIP_INST(6, 4, 64, 0, false, 64, SE_STORE, false, 3, 1, IDM_STRIP_WD, 11, 0, 2);

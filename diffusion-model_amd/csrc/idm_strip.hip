@@ -345,7 +345,7 @@ constexpr TallKind kTall[SK_COUNT] = {
     {8, true, 11, 0},      // SK_CONV3
     {0, false, 0, 0},      // SK_CONV4 (4 rows are 16 units already)
     {4, true, 13, 0},      // SK_CONV5
-    {0, false, 0, 0},      // SK_CONV6 (8 rows of its windows exceed the LDS of two workgroups per CU)
+    {8, true, 7, 11},      // SK_CONV6 (77 KB of windows: two workgroups per CU only without a staging tile of its own)
     {8, true, 11, 0},      // SK_CONV7
     {16, true, 6, 10},     // SK_CONV8
     {16, false, 10, 0},    // SK_CONV9 (its staging tile is the small score tile)
@@ -430,7 +430,7 @@ bool strip_fits(int kind, int R, int WS)
 
 hipError_t launch_strip(int kind, const StripArgs &a, hipStream_t s)
 {
-    static thread_local StripLaunch all_st[IDM_MAX_DEVICES][2 * SK_COUNT + 5];
+    static thread_local StripLaunch all_st[IDM_MAX_DEVICES][2 * SK_COUNT + 6];
     const int slot = idm_device_slot();
     if (slot < 0) return hipErrorInvalidDevice;
     StripLaunch *st = all_st[slot];
@@ -439,6 +439,7 @@ hipError_t launch_strip(int kind, const StripArgs &a, hipStream_t s)
         switch (kind) {
         case SK_CONV3: return launch_strip_one(st[T + 0], strip_kernel<64, 0, false, 64, SE_STORE_POOL, false, 4, 1, IDM_STRIP_WD, kTall[SK_CONV3].npa, 0, 2, 32, 8, true>, a, s);
         case SK_CONV5: return launch_strip_one(st[T + 1], strip_kernel<128, 0, false, 128, SE_STORE, false, 4, 1, IDM_STRIP_WD, kTall[SK_CONV5].npa, 0, 2, 32, 4, true>, a, s);
+        case SK_CONV6: return launch_strip_one(st[T + 5], strip_kernel<128, 64, true, 64, SE_STORE, false, 4, 1, IDM_STRIP_WD, kTall[SK_CONV6].npa, kTall[SK_CONV6].npb, 2, 32, 8, true>, a, s);
         case SK_CONV7: return launch_strip_one(st[T + 2], strip_kernel<64, 0, false, 64, SE_STORE, false, 4, 1, IDM_STRIP_WD, kTall[SK_CONV7].npa, 0, 2, 32, 8, true>, a, s);
         case SK_CONV8: return launch_strip_one(st[T + 3], strip_kernel<64, 32, true, 32, SE_STORE, false, 4, 1, IDM_STRIP_WD, kTall[SK_CONV8].npa, kTall[SK_CONV8].npb, 2, 32, 16, true>, a, s);
         default: return launch_strip_one(st[T + 4], strip_kernel<32, 0, false, 32, SE_HEAD, false, 4, 1, IDM_STRIP_WD, kTall[SK_CONV9].npa, 0, 2, 32, 16>, a, s);

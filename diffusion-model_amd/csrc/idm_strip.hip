@@ -352,8 +352,19 @@ constexpr TallKind kTall[SK_COUNT] = {
     {0, false, 0, 0},      // SK_CONV9S
     {0, false, 0, 0},      // SK_CONV9H2
 };
-inline bool is_tall(int kind, int R, int WS) { return WS == 32 && R > 0 && R == kTall[kind].rows; }
-inline bool is_alias(int kind, int R, int WS) { return is_tall(kind, R, WS) && kTall[kind].alias; }
+// Strips narrower than 32 columns (the spectral model's 20-column top level): 16-row bands fit without aliasing; the
+// instances take the strip width at run time and hold more prefetch registers.
+constexpr TallKind kTallNarrow[SK_COUNT] = {
+    {16, false, 9, 0},     // SK_CONV1
+    {0, false, 0, 0}, {0, false, 0, 0}, {0, false, 0, 0}, {0, false, 0, 0}, {0, false, 0, 0}, {0, false, 0, 0},
+    {16, false, 6, 9},     // SK_CONV8
+    {0, false, 0, 0},      // SK_CONV9
+    {0, false, 0, 0},      // SK_CONV9S
+    {16, false, 9, 0},     // SK_CONV9H2
+};
+inline const TallKind &tall_of(int kind, int WS) { return WS == 32 ? kTall[kind] : kTallNarrow[kind]; }
+inline bool is_tall(int kind, int R, int WS) { return WS >= 17 && R > 0 && R == tall_of(kind, WS).rows; }
+inline bool is_alias(int kind, int R, int WS) { return is_tall(kind, R, WS) && tall_of(kind, WS).alias; }
 
 struct StripLaunch {
     bool configured = false;
@@ -412,8 +423,8 @@ bool strip_fits(int kind, int R, int WS)
     const StripKind &k = kStrip[kind];
     int npa = k.npa, npb = k.npb;
     if (is_tall(kind, R, WS)) {
-        npa = kTall[kind].npa;
-        npb = kTall[kind].npb;
+        npa = tall_of(kind, WS).npa;
+        npb = tall_of(kind, WS).npb;
     }
     if (!k.up) return (R + 2) * (WS + 2) * (k.ca / 8) <= npa * WG;
     return (R / 2 + 2) * (WS / 2 + 2) * (k.ca / 8) <= npa * WG && (R + 2) * (WS + 2) * (k.cb / 8) <= npb * WG;
@@ -430,10 +441,18 @@ bool strip_fits(int kind, int R, int WS)
 
 hipError_t launch_strip(int kind, const StripArgs &a, hipStream_t s)
 {
-    static thread_local StripLaunch all_st[IDM_MAX_DEVICES][2 * SK_COUNT + 6];
+    static thread_local StripLaunch all_st[IDM_MAX_DEVICES][2 * SK_COUNT + 9];
     const int slot = idm_device_slot();
     if (slot < 0) return hipErrorInvalidDevice;
     StripLaunch *st = all_st[slot];
+    if (is_tall(kind, a.R, a.WS) && a.WS < 32) {
+        constexpr int T = 2 * SK_COUNT + 6;
+        switch (kind) {
+        case SK_CONV1: return launch_strip_one(st[T + 0], strip_kernel<32, 0, false, 32, SE_STORE_POOL, false, 4, 1, IDM_STRIP_WD, kTallNarrow[SK_CONV1].npa, 0, 2, 0, 0>, a, s);
+        case SK_CONV8: return launch_strip_one(st[T + 1], strip_kernel<64, 32, true, 32, SE_STORE, false, 4, 1, IDM_STRIP_WD, kTallNarrow[SK_CONV8].npa, kTallNarrow[SK_CONV8].npb, 2, 0, 0>, a, s);
+        default: return launch_strip_one(st[T + 2], strip_kernel<32, 0, false, 32, SE_HEAD2, false, 4, 1, IDM_STRIP_WD, kTallNarrow[SK_CONV9H2].npa, 0, 2, 0, 0>, a, s);
+        }
+    }
     if (is_tall(kind, a.R, a.WS)) {
         constexpr int T = 2 * SK_COUNT;
         switch (kind) {

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
     // fewer halo rows are re-read.  The output staging tile lies OVER the input windows; the epilogue therefore waits at a
     // barrier until every wavefront has issued its last MFMA (each runs exactly one piece, so all reach that barrier
     // once per item).
-    static_assert(!ALIAS || (WST == 32 && RT > 0 && NT == 4 && (EPI == SE_STORE || EPI == SE_STORE_POOL)), "aliased staging: store kernels with one piece per wavefront");
+    static_assert(!ALIAS || ((WST == 32 || WST == 16) && RT > 0 && NT == 4 && (EPI == SE_STORE || EPI == SE_STORE_POOL)), "aliased staging: store kernels with one piece per wavefront");
     // LDS map: [window a | window b | output staging | epilogue constants]
     char *tile_a = smem;
     char *tile_b = UP ? smem + ((((R >> 1) + 2) * ((WS >> 1) + 2) * SA + 15) & ~15) : nullptr;
@@ -362,8 +362,16 @@ constexpr TallKind kTallNarrow[SK_COUNT] = {
     {0, false, 0, 0},      // SK_CONV9S
     {16, false, 9, 0},     // SK_CONV9H2
 };
-inline const TallKind &tall_of(int kind, int WS) { return WS == 32 ? kTall[kind] : kTallNarrow[kind]; }
-inline bool is_tall(int kind, int R, int WS) { return WS >= 17 && R > 0 && R == tall_of(kind, WS).rows; }
+// 16-column strips (two row slots per tile) of conv5: 8-row bands are 16 work units; staging over the window.
+constexpr TallKind kTall16Conv5 = {8, true, 12, 0};
+inline const TallKind &tall_of(int kind, int WS)
+{
+    return WS == 32 ? kTall[kind] : WS == 16 && kind == SK_CONV5 ? kTall16Conv5 : kTallNarrow[kind];
+}
+inline bool is_tall(int kind, int R, int WS)
+{
+    return (WS >= 17 || (WS == 16 && kind == SK_CONV5)) && R > 0 && R == tall_of(kind, WS).rows;
+}
 inline bool is_alias(int kind, int R, int WS) { return is_tall(kind, R, WS) && tall_of(kind, WS).alias; }
 
 struct StripLaunch {
@@ -441,13 +449,14 @@ bool strip_fits(int kind, int R, int WS)
 
 hipError_t launch_strip(int kind, const StripArgs &a, hipStream_t s)
 {
-    static thread_local StripLaunch all_st[IDM_MAX_DEVICES][2 * SK_COUNT + 9];
+    static thread_local StripLaunch all_st[IDM_MAX_DEVICES][2 * SK_COUNT + 10];
     const int slot = idm_device_slot();
     if (slot < 0) return hipErrorInvalidDevice;
     StripLaunch *st = all_st[slot];
     if (is_tall(kind, a.R, a.WS) && a.WS < 32) {
         constexpr int T = 2 * SK_COUNT + 6;
         switch (kind) {
+        case SK_CONV5: return launch_strip_one(st[T + 3], strip_kernel<128, 0, false, 128, SE_STORE, false, 4, 1, IDM_STRIP_WD, kTall16Conv5.npa, 0, 2, 16, 8, true>, a, s);
         case SK_CONV1: return launch_strip_one(st[T + 0], strip_kernel<32, 0, false, 32, SE_STORE_POOL, false, 4, 1, IDM_STRIP_WD, kTallNarrow[SK_CONV1].npa, 0, 2, 0, 0>, a, s);
         case SK_CONV8: return launch_strip_one(st[T + 1], strip_kernel<64, 32, true, 32, SE_STORE, false, 4, 1, IDM_STRIP_WD, kTallNarrow[SK_CONV8].npa, kTallNarrow[SK_CONV8].npb, 2, 0, 0>, a, s);
         default: return launch_strip_one(st[T + 2], strip_kernel<32, 0, false, 32, SE_HEAD2, false, 4, 1, IDM_STRIP_WD, kTallNarrow[SK_CONV9H2].npa, 0, 2, 0, 0>, a, s);

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -94,6 +95,24 @@ static __device__ __align__(256) unsigned char scratch[IDM_NOALLOC_SCRATCH_BYTES
 
 namespace {
 char *g_scratch_ptr[IDM_MAX_DEVICES] = {};
+std::mutex g_scratch_mutex;   // handles may be created from several threads at once
+
+// Device address of this GPU's copy of `scratch`, resolved on first use (the device must be current).
+int scratch_address(int device, char **out)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) {
+            g_err = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+            return IDM_ERR_HIP;
+        }
+        g_scratch_ptr[device] = (char *)ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return IDM_OK;
+}
 }
 
 int idm_set_error(int code, const char *msg) { return fail(code, msg ? msg : ""); }
@@ -693,10 +712,20 @@ int idm_model_create(idm_model **out, int device, const idm_model_desc *d)
         return fail(IDM_ERR_UNSUPPORTED, std::string("built for gfx950 (MI355X); device is ") + prop.gcnArchName);
 
     if (device >= IDM_MAX_DEVICES) return fail(IDM_ERR_UNSUPPORTED, "device index beyond IDM_MAX_DEVICES");
-    if (!g_scratch_ptr[device]) {
-        void *ptr = nullptr;
-        HIPCHK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
-        g_scratch_ptr[device] = (char *)ptr;
+#ifdef IDM_EXPERIMENT
+    // A library built with a timing-experiment switch (IDM_EXP_*: proxies that compute WRONG results by design) must not
+    // pass for the product: handles are refused unless the measurement script says it knows what it loaded.
+    {
+        const char *allow = getenv("ISINGDIFF_ALLOW_EXPERIMENT");
+        if (!(allow && allow[0] == '1'))
+            return fail(IDM_ERR_UNSUPPORTED, "libisingdiff.so was built with -DIDM_EXPERIMENT (timing proxies, wrong results); "
+                                             "ISINGDIFF_ALLOW_EXPERIMENT=1 lets a measurement script use it");
+    }
+#endif
+    {
+        char *unused = nullptr;
+        int rc0 = scratch_address(device, &unused);
+        if (rc0 != IDM_OK) return rc0;
     }
 
     idm_model *m = new idm_model();
@@ -812,6 +841,16 @@ int idm_forward_taps(idm_model *m, const float *x_dev, float t_norm, float *scor
     return IDM_OK;
 }
 
+int idm_plan_chunk(idm_model *m, int64_t B, int H, int W, int precision, int64_t *chunk_out, int64_t *bytes_per_lattice_out)
+{
+    int rc = check_shape(m, B, H, W, precision);
+    if (rc != IDM_OK) return rc;
+    const Plan p = make_plan(m, H, W, precision);
+    if (chunk_out) *chunk_out = auto_chunk(p, B);
+    if (bytes_per_lattice_out) *bytes_per_lattice_out = (int64_t)p.per_lattice;
+    return IDM_OK;
+}
+
 int idm_forward(idm_model *m, const float *x_dev, float t_norm, float *score_dev, int64_t B, int H, int W,
                 int precision, void *stream)
 {
@@ -825,8 +864,9 @@ int idm_forward_noalloc(idm_model *m, const float *x_dev, float t_norm, float *s
     if (rc != IDM_OK) return rc;
     if (!x_dev || !score_dev) return fail(IDM_ERR_INVALID, "null tensor");
     HIPCHK(hipSetDevice(m->device));
-    char *ws = g_scratch_ptr[m->device];
-    if (!ws) return fail(IDM_ERR_HIP, "static scratch address was not resolved for this device");
+    char *ws = nullptr;
+    rc = scratch_address(m->device, &ws);   // resolved by idm_model_create; a lookup under the mutex here
+    if (rc != IDM_OK) return rc;
     const Plan p = make_plan(m, H, W, precision);
     if (p.per_lattice * (size_t)B > (size_t)IDM_NOALLOC_SCRATCH_BYTES)
         return fail(IDM_ERR_INVALID, "idm_forward_noalloc: " + std::to_string(B) + " lattices of " + std::to_string(H) + "x" +

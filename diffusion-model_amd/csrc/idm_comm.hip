@@ -63,6 +63,18 @@ struct idm_comm {
     std::vector<nccl_comm_t> comms;   // empty for a single device
 };
 
+namespace {
+
+// Both multi-device calls walk the devices with hipSetDevice (ncclCommInitAll does so itself); the caller's current
+// device is put back on every return path, so that its following idm_* and HIP calls land where they did before.
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
+}  // namespace
+
 extern "C" {
 
 int idm_comm_create(idm_comm **out, const int *devices, int n)
@@ -79,6 +91,7 @@ int idm_comm_create(idm_comm **out, const int *devices, int n)
     idm_comm *c = new idm_comm();
     c->devices.assign(devices, devices + n);
     if (n > 1) {
+        DeviceGuard guard;
         std::string why;
         Rccl *r = load_rccl(&why);
         if (!r) { delete c; return idm_set_error(IDM_ERR_UNSUPPORTED, why.c_str()); }
@@ -103,6 +116,7 @@ int idm_allreduce_i64(idm_comm *c, int64_t *const *per_device_bufs, size_t count
     if (n == 1) return IDM_OK;   // the sum over one rank
     Rccl *r = load_rccl(nullptr);
     if (!r) return idm_set_error(IDM_ERR_UNSUPPORTED, "librccl.so is not loaded");
+    DeviceGuard guard;
     int rc = r->group_start();
     for (int i = 0; i < n && rc == 0; ++i) {
         if (hipSetDevice(c->devices[i]) != hipSuccess) { rc = -1; break; }

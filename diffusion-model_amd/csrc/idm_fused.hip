@@ -721,7 +721,7 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
 
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
 {
-    static thread_local LaunchState all_st[IDM_MAX_DEVICES][10];
+    static thread_local LaunchState all_st[IDM_MAX_DEVICES][11];   // one slot per kernel FUNCTION (attributes and occupancy are per function)
     const int slot = idm_device_slot();
     if (slot < 0) return hipErrorInvalidDevice;
     LaunchState *st = all_st[slot];
@@ -732,7 +732,7 @@ hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
         // whole-map instance: the staging tile lies over the mid tile, so the input region holds the input tile only
         FusedArgs b = a;
         b.lds_in_bytes = align16((16 + 4) * (16 + 2) * (32 * 2 + 16));
-        return launch_one(st[6], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1W, 16, 16>, b, B, s);
+        return launch_one(st[10], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1W, 16, 16>, b, B, s);
     }
     if (spec) {
         switch (kind) {

@@ -336,6 +336,12 @@ __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
         // (a wavefront's third tile, in a lattice's nine-row top band, is finished at once).  Stores of a stream without
         // work go to a scratch area behind the constants.
         static_assert(BIAS_IN_ACC && NT1 == 3 && NT2 == 2, "deferred epilogues assume the bias in the accumulators");
+        // The deferred sinks below store both pending tiles of a piece unconditionally (to dst and dst + one row): they
+        // ignore the `valid` flag ConvStage::piece hands them.  That is correct only while every tile of every piece lies
+        // inside its band: one row per 32-pixel tile (W == 32, so TR == 1), EXACT stages, and conv8 pieces of exactly two
+        // or three rows that never run past the band's rows.  Any other band geometry must carry `valid` with the
+        // pending piece and send an invalid tile's stores to `dummy`.
+        static_assert(W == 32 && R == 8, "the deferred sinks assume one row per tile and full eight-row bands");
         using Conv1 = ConvStage<CA, CB, true, C1, NT1, 1, WD1, false, true>;
         using Conv2 = ConvStage<C1, 0, false, C2, NT2, 1, WD2, true, true>;
         Conv1 cs1;

@@ -17,7 +17,7 @@ IDM_UPDATE_SCORE = 0
 IDM_UPDATE_DDPM = 1
 NCONV = 11
 NDENSE = 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 NOALLOC_SCRATCH_BYTES = 64 << 20
 
 
@@ -77,6 +77,7 @@ SIGNATURES = {
     "idm_time_table": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "idm_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "idm_forward_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "idm_plan_chunk": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "idm_forward_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                    C.POINTER(C.c_void_p), C.c_void_p]),
     "idm_sample": (C.c_int, [C.c_void_p, C.POINTER(SampleCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

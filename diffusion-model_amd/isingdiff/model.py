@@ -161,6 +161,13 @@ class ScoreModel:
         """Tuning switch, e.g. ``set_option("fused", 0)`` forces one kernel per layer in bf16."""
         _lib.check(_lib.load().idm_set_option(self.handle, name.encode(), int(value)))
 
+    def plan_chunk(self, B: int, H: int, W: int, precision=None):
+        """How a batch of ``B`` lattices will be cut: ``(lattices per chunk, workspace bytes per lattice)``."""
+        prec = self.precision if precision is None else _precision_code(precision)
+        chunk, per = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.load().idm_plan_chunk(self.handle, int(B), int(H), int(W), prec, C.byref(chunk), C.byref(per)))
+        return chunk.value, per.value
+
     def profile_begin(self):
         """Start per-kernel event timing of this model's launches (see idm_profile_begin)."""
         with torch.cuda.device(self.device):

@@ -26,9 +26,10 @@ UPDATE_RULES = {"score": _lib.IDM_UPDATE_SCORE, "ddpm": _lib.IDM_UPDATE_DDPM}
 
 
 def alpha_cumprod(beta_lst) -> np.ndarray:
-    """``float32(np.cumprod(1 - noise_beta))`` (:169-173), in the precision ``beta_lst`` comes in (the reference's
-    ``noise_beta`` is float64)."""
-    return np.cumprod(1.0 - np.asarray(beta_lst)).astype(np.float32)
+    """``float32(np.cumprod(1 - noise_beta))`` (:169-173).  The product is taken in float64 whatever ``beta_lst`` comes
+    in and cast last, as the reference does with its float64 ``noise_beta``: given the float64 schedule this is the
+    reference's array exactly; given float32 betas it is what the library computes when handed none."""
+    return np.cumprod(1.0 - np.asarray(beta_lst, np.float64)).astype(np.float32)
 
 
 def _run(model: ScoreModel, x: torch.Tensor, betas: np.ndarray, T: int, *, noise: Optional[torch.Tensor],

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define IDM_ABI_VERSION 2
+#define IDM_ABI_VERSION 3
 
 typedef enum {
     IDM_OK = 0,
@@ -91,8 +91,11 @@ typedef struct {
     int64_t chunk;                /* lattices processed together (bounds the workspace); 0 = automatic */
     int32_t update_rule;          /* idm_update_rule; 0 = the rule the reference runs (:96) */
     int32_t reserved;
-    const float *alpha_cumprod_host; /* IDM_UPDATE_DDPM: T float32 values alpha_cumprod[t] (:170-173), or NULL to have
-                                        them computed as float32(cumprod(1 - betas)) in double precision */
+    const float *alpha_cumprod_host; /* IDM_UPDATE_DDPM: T float32 values alpha_cumprod[t] (:169-173), or NULL to have
+                                        them computed as float32(cumprod(1 - double(betas_host[t]))) in double precision.
+                                        The reference takes the product over its float64 schedule and casts last: a caller
+                                        that holds the float64 betas passes float32(np.cumprod(1 - betas64)) here to match
+                                        it exactly; NULL starts from the float32 betas and can differ from that by an ulp */
 } idm_sample_cfg;
 
 int idm_abi_version(void);
@@ -120,9 +123,21 @@ int idm_forward(idm_model *m, const float *x_dev, float t_norm, float *score_dev
  * message states the largest B for that shape and precision; e.g. 390 lattices at L = 32 in bf16, 173 at
  * L = 20 in float32).  All handles on one GPU share the array: calls that overlap on one GPU (different
  * streams or threads) race; order them on one stream.  Per-kernel profiling is not recorded for these calls. */
+/* What else the call touches: like every call on a handle it makes the handle's device current (hipSetDevice) and
+ * rewrites the handle's time-embedding row (shared with idm_forward, hence the ordering rule above); the first
+ * launch of each kernel function in a thread sets that function's LDS attribute and reads its occupancy (host-side
+ * queries, legal under stream capture).  Captured into a HIP graph the call replays with the captured t_norm and
+ * pointers; tests/test_zz_no_alloc.py captures a first call on a fresh handle and shape and replays it. */
 #define IDM_NOALLOC_SCRATCH_BYTES (64u << 20)
 int idm_forward_noalloc(idm_model *m, const float *x_dev, float t_norm, float *score_dev,
                         int64_t B, int H, int W, int precision, void *stream);
+
+/* How idm_forward / idm_sample will cut a batch of B lattices of this shape and precision (no counterpart in the
+ * reference, whose batch is one tensor): *chunk_out = lattices processed together (the fewest equal chunks whose
+ * activation workspace fits the library's budget; B itself when one chunk suffices), *bytes_per_lattice_out = the
+ * workspace a lattice needs.  Either pointer may be NULL.  Launches nothing. */
+int idm_plan_chunk(idm_model *m, int64_t B, int H, int W, int precision, int64_t *chunk_out,
+                   int64_t *bytes_per_lattice_out);
 
 /* Optional taps for tests: like idm_forward, and copies layer i's activation (padded size,
  * float32, (B,h_i,w_i,c_i)) to taps_dev[i] for every non-NULL entry, i = 0..10. */

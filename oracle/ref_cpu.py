@@ -27,7 +27,7 @@ def build(force: bool = False) -> str:
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libref_cpu.so")
+        so = os.environ.get("ISINGDIFF_REF_LIB") or os.path.join(_HERE, "libref_cpu.so")   # (the sanitizer build: make asan-test)
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)

@@ -7,11 +7,18 @@ does not travel to the GPU box, the small .npz files written here do):
   reference_ifft_L{L}.npz    random (non-Hermitian) half spectra and ising_ifft(spec, L) of
                              /root/reference/b_fft.py:12-17, plus ising_fft of +-1 lattices (:4-9)
 
-The two modules need only numpy / scipy and define functions without side effects at import.
+  reference_observables.npz  ising_energy / ising_magnetization of
+                             /root/reference/b_pure_metoropolis_2d_ising.py:42-60 on random and hand-made +-1 lattices
+
+onsager.py and b_fft.py need only numpy / scipy and define functions without side effects at import.
+b_pure_metoropolis_2d_ising.py cannot be imported (its line 4 imports a plotting package that is not installed, and
+the module runs a temperature sweep at import), so the two function definitions - pure numpy - are taken out of its
+syntax tree and compiled alone, with numpy as their only global; nothing else of the file runs.
 
     python tests/golden/make_reference_fixtures.py [--reference /root/reference]
 """
 import argparse
+import ast
 import importlib.util
 import os
 
@@ -27,10 +34,45 @@ def load(path, name):
     return mod
 
 
+def extract_functions(path, names):
+    """Compile only the named top-level function definitions of a Python source file (numpy as `np` in scope)."""
+    with open(path, encoding="utf-8") as f:
+        tree = ast.parse(f.read(), filename=path)
+    picked = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in picked) == sorted(names), [n.name for n in picked]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def observables_fixture(reference):
+    src = os.path.join(reference, "b_pure_metoropolis_2d_ising.py")
+    ising_energy, ising_magnetization = extract_functions(src, ["ising_energy", "ising_magnetization"])
+    out = {}
+    for L, B in ((4, 64), (20, 48), (32, 40), (64, 12), (128, 4)):
+        rs = np.random.RandomState(2000 + L)
+        p_up = rs.uniform(0.05, 0.95, size=(B, 1, 1))           # from nearly ordered to disordered lattices
+        spins = np.where(rs.uniform(size=(B, L, L)) < p_up, 1, -1).astype(np.int8)
+        yy, xx = np.meshgrid(np.arange(L), np.arange(L), indexing="ij")
+        spins[0] = 1
+        spins[1] = -1
+        spins[2] = np.where((yy + xx) % 2 == 0, 1, -1)          # checkerboard: E = +2 L^2
+        spins[3] = np.where(yy % 2 == 0, 1, -1)                 # stripes: vertical bonds -, horizontal bonds +
+        x = spins.astype(np.float64)
+        out[f"spins_L{L}"] = spins
+        out[f"energy_J1_h0_L{L}"] = np.asarray(ising_energy(x, 1.0, 0.0), np.float64)
+        out[f"energy_J05_h03_L{L}"] = np.asarray(ising_energy(x, 0.5, 0.3), np.float64)
+        out[f"energy_int8_J1_h0_L{L}"] = np.asarray(ising_energy(spins.astype(np.int64), 1, 0), np.float64)
+        out[f"magnetization_L{L}"] = np.asarray(ising_magnetization(x), np.float64)
+    np.savez_compressed(os.path.join(HERE, "reference_observables.npz"), **out)
+    print("wrote reference_observables.npz", {k: v.shape for k, v in out.items() if k.startswith("energy_J1")})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     args = ap.parse_args()
+    observables_fixture(args.reference)
     ons = load(os.path.join(args.reference, "onsager.py"), "reference_onsager")
     fft = load(os.path.join(args.reference, "b_fft.py"), "reference_b_fft")
 

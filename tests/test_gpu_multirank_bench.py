@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("L,B", [(32, 96), (64, 24)])
+@pytest.mark.parametrize("L,B", [(32, 96), (64, 24), (128, 6)])
 def test_two_rank_bench_matches_one_rank(tmp_path, gpu_real, L, B):
     import torch
     from isingdiff import beta_schedule, sample
@@ -48,6 +48,41 @@ def test_two_rank_bench_matches_one_rank(tmp_path, gpu_real, L, B):
     torch.cuda.synchronize()
     assert np.array_equal(got, res.spins.cpu().numpy())
     assert abs(rec["observables"]["mean_E_per_site"] - res.observables.mean_energy_per_site()) < 1e-12
+
+
+def _run_bench(tmp_path, tag, ranks, extra):
+    prefix = str(tmp_path / tag)
+    env = dict(os.environ, ISINGDIFF_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    if ranks > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port())]
+    else:
+        cmd = [sys.executable]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+            "--dump-spins", prefix] + extra
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0]), np.concatenate([np.load(f"{prefix}.rank{r}.npy") for r in range(ranks)])
+
+
+@pytest.mark.parametrize("workload,B,extra", [("bitflip", 40, []), ("spectral", 24, ["--T", "12"]), ("dense", 96, ["--T", "12"])])
+def test_two_rank_bench_of_the_other_workloads(tmp_path, workload, B, extra):
+    """bench.py --workload bitflip | spectral | dense (BASELINE configs 5 and 4, and the dense spectral model) through
+    the same multi-rank launch: two ranks of B units equal one rank of 2B units bit for bit (inputs and random numbers
+    are keyed by the global index), the all-reduced histogram counts 2B units, one JSON line with `roofline`."""
+    two, got2 = _run_bench(tmp_path, "two", 2, ["--workload", workload, "--batch", str(B)] + extra)
+    one, got1 = _run_bench(tmp_path, "one", 1, ["--workload", workload, "--batch", str(2 * B)] + extra)
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and one["n_gpus"] == 1
+    assert two["observables"]["units_in_histogram"] == 2 * B == one["observables"]["units_in_histogram"]
+    assert two["roofline"] is not None and two["roofline"]["frac"] > 0
+    assert got2.shape == got1.shape and np.array_equal(got2, got1)
+    key = "mean_final_pixel" if workload == "bitflip" else "mean_E_per_site"
+    assert abs(two["observables"][key] - one["observables"][key]) < 1e-12
+    if workload == "bitflip":
+        assert two["config"]["T"] == 100 and "full schedule" in two["metric"]
+        assert 0.0 < two["observables"][key] < 1.0
 
 
 def test_in_library_allreduce_single_device():

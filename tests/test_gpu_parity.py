@@ -219,20 +219,28 @@ def test_sampler_ddpm_update_rule(gpu_real, ref_real):
         sample(gpu_real, 4, 20, T=10, update_rule="euler")
 
 
-def test_sampler_matches_golden(gpu_real):
-    """Committed fixture (tests/golden/make_golden.py): B=4, L=20, RandomState(0) noise."""
+@pytest.mark.parametrize("B,L", [(4, 20), (2, 32)])
+def test_sampler_matches_golden(gpu_real, B, L):
+    """Committed fixtures (tests/golden/make_golden.py), RandomState(0) noise, the full 1000-step free run in float32:
+    B=4 at L=20 (the size the weights were trained at) and B=2 at L=32 (the headline lattice size).  Scores at four
+    steps, the final state, spins, M and S, bit for bit."""
     import os
+    import torch
     from isingdiff.sampler import beta_schedule, diffusion_backward
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "realspace_B4_L20_seed0.npz"))
-    B, L, T = 4, 20, 1000
+    from isingdiff.observables import observe
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"realspace_B{B}_L{L}_seed0.npz"))
+    T = 1000
     rs = np.random.RandomState(0)
     x_T = rs.standard_normal((B, L, L, 1)).astype(np.float32)
     z = rs.standard_normal((T, B, L, L, 1)).astype(np.float32)
     traj, scores = diffusion_backward(x_T, beta_schedule(T), gpu_real, T, noise=z, precision="fp32", return_scores=True)
     for t in (999, 900, 500, 0):
-        assert np.array_equal(scores[t].reshape(B, -1), g[f"score_t{t}"])
+        assert np.array_equal(scores[t].reshape(B, -1), g[f"score_t{t}"]), t
+    assert np.array_equal(traj[0].reshape(B, -1).view(np.uint32), g["x_final"].view(np.uint32))
     spins = np.where(traj[0] > 0, 1, -1).astype(np.int8).reshape(B, L, L)
     assert np.array_equal(spins, g["spins"])
+    obs = observe(torch.from_numpy(spins).cuda())
+    assert np.array_equal(obs.M.cpu().numpy(), g["M"]) and np.array_equal(obs.S.cpu().numpy(), g["S"])
 
 
 def test_sampler_bf16_teacher_forced(gpu_real, ref_real):
@@ -341,6 +349,24 @@ def test_observables_exact(L):
     assert np.allclose(obs.magnetization(), s.mean((1, 2)))
 
 
+@pytest.mark.parametrize("L", [4, 20, 32, 64, 128])
+def test_observables_match_reference_outputs(L):
+    """idm_observe against OUTPUTS of the reference's own ising_energy / ising_magnetization
+    (b_pure_metoropolis_2d_ising.py:42-60, run on these lattices by tests/golden/make_reference_fixtures.py)."""
+    import os
+    import torch
+    from isingdiff.observables import observe, ising_energy, ising_magnetization
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_observables.npz"))
+    spins = g[f"spins_L{L}"]
+    obs = observe(torch.from_numpy(spins).cuda())
+    assert np.array_equal(obs.energy(1.0, 0.0), g[f"energy_J1_h0_L{L}"])
+    assert np.allclose(obs.energy(0.5, 0.3), g[f"energy_J05_h03_L{L}"], rtol=0, atol=1e-9)
+    assert np.allclose(obs.magnetization(), g[f"magnetization_L{L}"], rtol=0, atol=1e-15)
+    # the drop-in functions with the reference's names and argument order
+    assert np.array_equal(ising_energy(spins, 1.0, 0.0), g[f"energy_J1_h0_L{L}"])
+    assert np.allclose(ising_magnetization(spins), g[f"magnetization_L{L}"], rtol=0, atol=1e-15)
+
+
 def test_sample_philox_shard_independent(gpu_real):
     """sample() on [0,6) equals sample() on [0,3) and [3,6) with global indices (fp32, short schedule)."""
     from isingdiff.sampler import sample, beta_schedule
@@ -368,8 +394,12 @@ def test_full_size_batch_properties(gpu_real):
     betas = beta_schedule(1000)[:T]
     full = sample(gpu_real, n, L, T=T, betas=betas, seed=11, precision="bf16", keep_state=True)
     assert full.x_final.shape == (n, L, L, 1) and bool(torch.isfinite(full.x_final).all())
-    # windows around the chunk boundary (10 923 lattices per chunk), the ends and the middle
-    for g0, cnt in ((0, 5), (10920, 7), (32768, 3), (65531, 5)):
+    # windows that straddle every chunk boundary of the plan (taken from the library: the last lattices of one chunk
+    # and the first of the next), both ends of the batch and the middle of the first chunk
+    chunk, _ = gpu_real.plan_chunk(n, L, L, precision="bf16")
+    assert 1024 <= chunk < n and n % chunk == 0, chunk          # the bench batch runs as several equal chunks
+    windows = [(0, 5), (chunk // 2 - 3, 7), (n - 5, 5)] + [(k - 4, 7) for k in range(chunk, n, chunk)]
+    for g0, cnt in windows:
         part = sample(gpu_real, cnt, L, T=T, betas=betas, seed=11, precision="bf16", keep_state=True, first_global_index=g0)
         assert torch.equal(full.x_final[g0:g0 + cnt], part.x_final), g0
         assert torch.equal(full.spins[g0:g0 + cnt], part.spins), g0

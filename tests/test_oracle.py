@@ -69,12 +69,13 @@ def test_fft_unet_c_vs_torch(fft_spec):
     assert np.abs(got - want).max() / np.abs(want).max() < 2e-5
 
 
-def test_oracle_reproduces_golden_fixture(ref_real):
-    """tests/golden/realspace_B4_L20_seed0.npz (made by tests/golden/make_golden.py): the oracle is
-    deterministic bit for bit, independent of thread count and build."""
+@pytest.mark.parametrize("B,L", [(4, 20), (2, 32)])
+def test_oracle_reproduces_golden_fixture(ref_real, B, L):
+    """tests/golden/realspace_B4_L20_seed0.npz and realspace_B2_L32_seed0.npz (made by tests/golden/make_golden.py):
+    the oracle is deterministic bit for bit, independent of thread count and build."""
     from oracle import ref_cpu
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "realspace_B4_L20_seed0.npz"))
-    B, L, T = 4, 20, 1000
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"realspace_B{B}_L{L}_seed0.npz"))
+    T = 1000
     rs = np.random.RandomState(0)
     x_T = rs.standard_normal((B, L, L, 1)).astype(np.float32)
     z = rs.standard_normal((T, B, L, L, 1)).astype(np.float32)
@@ -128,6 +129,23 @@ def test_observables_match_reference_formulas(L):
     assert np.array_equal(-1.0 * S - 0.0 * M, -1.0 * inter - 0.0 * f.sum((1, 2)))
     assert np.allclose(M / L ** 2, f.mean((1, 2)))
     assert S[0] == 2 * L * L and M[0] == L * L
+
+
+@pytest.mark.parametrize("L", [4, 20, 32, 64, 128])
+def test_observables_match_reference_outputs(L):
+    """The oracle's integer sums against OUTPUTS of the reference's own ising_energy / ising_magnetization
+    (b_pure_metoropolis_2d_ising.py:42-60; tests/golden/make_reference_fixtures.py took the two definitions out of the
+    file's syntax tree and ran them on these lattices): E = -J*S - h*M and m = M / L^2, exactly."""
+    import os
+    from oracle import ref_cpu
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_observables.npz"))
+    spins = g[f"spins_L{L}"]
+    M, S = ref_cpu.observe(spins)
+    assert np.array_equal(-1.0 * S - 0.0 * M, g[f"energy_J1_h0_L{L}"])
+    assert np.array_equal(-1.0 * S, g[f"energy_int8_J1_h0_L{L}"])
+    assert np.allclose(-0.5 * S - 0.3 * M, g[f"energy_J05_h03_L{L}"], rtol=0, atol=1e-9)
+    assert np.allclose(M / float(L * L), g[f"magnetization_L{L}"], rtol=0, atol=1e-15)
+    assert g[f"energy_J1_h0_L{L}"][0] == -2 * L * L and g[f"energy_J1_h0_L{L}"][2] == 2 * L * L
 
 
 def test_philox_known_answer():

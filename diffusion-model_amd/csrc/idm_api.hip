@@ -56,6 +56,24 @@ std::vector<uint16_t> pack_weights_bf16(const float *w, int cin, int cout)
     return p;
 }
 
+// Keras kernel (3,3,Cin,Cout) -> bf16 A-fragments of v_mfma_f32_16x16x32_bf16, [tap][c/32][cout/16][lane][8]:
+// lane l holds W[tap][32*cg + 8*(l>>4) + j][16*mt + (l&15)], j = 0..7.
+std::vector<uint16_t> pack_weights_bf16_m16(const float *w, int cin, int cout)
+{
+    const int ncg = cin / 32, mt = cout / 16;
+    std::vector<uint16_t> p((size_t)9 * cin * cout);
+    size_t o = 0;
+    for (int tap = 0; tap < 9; ++tap)
+        for (int cg = 0; cg < ncg; ++cg)
+            for (int m = 0; m < mt; ++m)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = cg * 32 + 8 * (l >> 4) + j, co = m * 16 + (l & 15);
+                        p[o++] = bf16_bits(w[((size_t)tap * cin + c) * cout + co]);
+                    }
+    return p;
+}
+
 // Keras kernel -> float A operands of v_mfma_f32_32x32x2_f32, [tap][c/8][mt][lane][4]:
 // element s of lane l is W[tap][8*cg + 2*s + (l>>5)][32*mt + (l&31)].
 std::vector<float> pack_weights_f32(const float *w, int cin, int cout)
@@ -121,6 +139,8 @@ std::vector<float> idm_pack_weights_f32(const float *w, int cin, int cout) { ret
 
 std::vector<uint16_t> idm_pack_weights_bf16(const float *w, int cin, int cout) { return pack_weights_bf16(w, cin, cout); }
 
+std::vector<uint16_t> idm_pack_weights_bf16_m16(const float *w, int cin, int cout) { return pack_weights_bf16_m16(w, cin, cout); }
+
 std::vector<float> idm_pack_weights_f32_1x1(const float *w, int cin, int cout)
 {
     const int ncg = cin / 8, mt = cout / 32;
@@ -145,6 +165,7 @@ struct idm_model {
     float *w_head = nullptr;               // (F, C) float32
     void *wpack_f32[IDM_NCONV] = {};       // layers 1..9
     void *wpack_bf16[IDM_NCONV] = {};
+    void *wpack_m16[IDM_NCONV] = {};       // layers whose fused kernel has a 16x16x32-MFMA instance (conv6)
     void *wpack_fold[IDM_NCONV] = {};      // BatchNorm models: bf16 pack of W*scale (strip kernels)
     float *bias_fold[IDM_NCONV] = {};      // bias*scale + shift
     float *bias[IDM_NCONV] = {};
@@ -456,6 +477,7 @@ int forward_fused(idm_model *m, const Plan &p, const float *x, const float *tadd
     void *c2 = buf(p.off_a6), *c4 = buf(p.off_a4), *c6 = buf(p.off_a6), *c8 = buf(p.off_a8);
     auto layer = [&](FusedArgs &a, int l1, int l2) {
         a.w1 = l1 == 0 ? m->w_first_pack : m->wpack_bf16[l1];
+        a.w1_alt = m->wpack_m16[l1];
         a.b1 = m->bias[l1];
         a.w2 = m->wpack_bf16[l2]; a.b2 = m->bias[l2];
     };
@@ -757,6 +779,10 @@ int idm_model_create(idm_model **out, int device, const idm_model_desc *d)
             std::vector<float> pf = pack_weights_f32(d->conv_w[i], cin[i], cout[i]);
             rc = upload(m, pb.data(), pb.size(), (uint16_t **)&m->wpack_bf16[i]);
             if (rc == IDM_OK) rc = upload(m, pf.data(), pf.size(), (float **)&m->wpack_f32[i]);
+            if (rc == IDM_OK && i == 6 && !m->bn) {
+                std::vector<uint16_t> p16 = pack_weights_bf16_m16(d->conv_w[i], cin[i], cout[i]);
+                rc = upload(m, p16.data(), p16.size(), (uint16_t **)&m->wpack_m16[i]);
+            }
             if (rc == IDM_OK && m->bn) {
                 // inference BatchNorm folded into the convolution: (W x + b)*s + h = (W*s) x + (b*s + h)
                 std::vector<float> wf((size_t)9 * cin[i] * cout[i]), bf_(cout[i]);

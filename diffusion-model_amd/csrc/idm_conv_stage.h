@@ -500,9 +500,12 @@ struct ConvStage {
 // (zeros outside [0,Hmap)); store() writes them into the tile (row t = global row g0+t) and clears
 // (unless HALO is false) the tile's two halo columns.  Splitting the two lets the loads of the next band fly while the
 // current band is still being computed.
-template <int C, int NP, int WGS = WG>
+// PAD: bytes between the channels of neighbouring positions.  16 (position stride an odd number of 16-byte units) suits
+// the operand reads of the 32x32x16 MFMA; 32 (stride = 2 mod 4 units) those of the 16x16x32 MFMA, whose ds_read_b128
+// lane groups mix two 8-channel blocks of 16 pixels each.
+template <int C, int NP, int WGS = WG, int PAD = 16>
 struct TileRegs {
-    static constexpr int S = C * 2 + 16, CH = C / 8;
+    static constexpr int S = C * 2 + PAD, CH = C / 8;
     bf16x8 v[NP];
 
     // src: this lattice's map (Hmap rows); rows outside it, and items beyond the tile, read as zero
@@ -563,10 +566,10 @@ struct TileRegs {
 };
 
 // Zeroes the halo columns of rows [0,nrows) and the whole of rows [z0,z1) of an LDS tile.
-template <int C, int WGS = WG>
+template <int C, int WGS = WG, int PAD = 16>
 DEVI void clear_halo(char *tile, int W, int nrows, int z0, int z1, int tid)
 {
-    constexpr int S = C * 2 + 16, CH = C / 8;
+    constexpr int S = C * 2 + PAD, CH = C / 8;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     for (int i = tid; i < nrows * 2 * CH; i += WGS) {
         const int ch = i % CH, side = (i / CH) & 1, r = i / (2 * CH);

@@ -11,6 +11,8 @@ int idm_set_error(int code, const char *msg);
 // Keras kernel (3,3,Cin,Cout) -> float A operands of v_mfma_f32_32x32x2_f32, [tap][c/8][mt][lane][4].
 std::vector<float> idm_pack_weights_f32(const float *w, int cin, int cout);
 std::vector<uint16_t> idm_pack_weights_bf16(const float *w, int cin, int cout);   // (3,3,Cin,Cout) -> bf16 MFMA A fragments
+// the same as A fragments of v_mfma_f32_16x16x32_bf16: [tap][c/32][cout/16][lane][8], lane l = cout l & 15, channels 8 (l >> 4) .. +7
+std::vector<uint16_t> idm_pack_weights_bf16_m16(const float *w, int cin, int cout);
 // the same for a (Cin,Cout) 1x1 kernel: one tap
 std::vector<float> idm_pack_weights_f32_1x1(const float *w, int cin, int cout);
 
@@ -105,6 +107,7 @@ struct FusedArgs {
     const void *in_a;  // PLAIN: (B,H,W,CA); UPCAT: (B,H/2,W/2,CA); FIRST: x float32 (B,Hx,Wx)
     const void *in_b;  // UPCAT: (B,H,W,CB)
     const void *w1;
+    const void *w1_alt;        // FK_M3: conv6's weights packed for v_mfma_f32_16x16x32_bf16 ([tap][ch/32][cout/16][lane][8]), or null
     const float *b1, *tadd1;   // bias; per-channel add after the activation (FK_M2 only)
     const void *w2;
     const float *b2;

@@ -474,3 +474,46 @@ def test_copy_wavefront_kernels_are_bit_identical_to_the_four_wavefront_ones(gpu
             got = np.load(tmp_path / f"{tag}{B}.npy")
             assert np.isfinite(got).all()
             assert np.array_equal(got, want), (tag, B)
+
+
+def test_conv6_on_the_16x16x32_mfma_matches_the_32x32x16_kernel(gpu_real, real_spec, ref_real, tmp_path):
+    """ISINGDIFF_M3_MFMA16=1 runs conv6 of the L=32 bf16 sampler on v_mfma_f32_16x16x32_bf16 (other operand lane maps,
+    input tiles with a 32-byte pad and a shared zero row, weights packed per 16 couts x 32 channels).  Same products,
+    another summation order: conv7's map within 4e-3 relative L2 of the default kernel's (bf16 rounding of conv6's
+    output can move by an ulp), the score within the bf16 tolerances of the oracle, for batches that leave workgroups
+    with zero, one and several lattices; three sampler steps stay within 1e-2.  (The switch is read once per process.)"""
+    import os, subprocess, sys
+    from oracle import ref_cpu
+    from isingdiff.sampler import sample, beta_schedule
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {os.path.join(root, 'diffusion-model_amd')!r})\n"
+        "from isingdiff import load_model, sample, beta_schedule\n"
+        f"m = load_model({os.path.join(root, 'weights', 'b_diffusion_model_2d_ising_realspace_unet.keras')!r}, device=0, precision='bf16')\n"
+        "for B in (1, 5, 300):\n"
+        "    x = np.load(os.path.join(sys.argv[1], f'x{B}.npy'))\n"
+        "    s, taps = m.forward_taps(x, np.float32(0.6), precision='bf16')\n"
+        "    np.save(os.path.join(sys.argv[1], f's{B}.npy'), s.cpu().numpy())\n"
+        "    np.save(os.path.join(sys.argv[1], f't{B}.npy'), taps[7].cpu().numpy())\n"
+        "r = sample(m, 777, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision='bf16', keep_state=True)\n"
+        "np.save(os.path.join(sys.argv[1], 'xs.npy'), r.x_final.cpu().numpy())\n")
+    rng = np.random.default_rng(61)
+    xs = {}
+    for B in (1, 5, 300):
+        xs[B] = ising_like(rng, B, 32, 32, 600)
+        np.save(tmp_path / f"x{B}.npy", xs[B])
+    assert "ISINGDIFF_M3_MFMA16" not in os.environ
+    subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, env=dict(os.environ, ISINGDIFF_M3_MFMA16="1"), timeout=240)
+    refq = ref_cpu.RefModel(real_spec, quant_bf16=True)
+    for B in (1, 5, 300):
+        want_s, want_t = gpu_real.forward_taps(xs[B], np.float32(0.6), precision="bf16")
+        got_s, got_t = np.load(tmp_path / f"s{B}.npy"), np.load(tmp_path / f"t{B}.npy")
+        assert np.isfinite(got_s).all() and np.isfinite(got_t).all()
+        assert rel_l2(got_t, want_t[7].cpu().numpy()) < 4e-3, B
+        assert rel_l2(got_s, want_s.cpu().numpy()) < 1e-2, B
+        if B <= 5:
+            assert rel_l2(got_s, refq.forward(xs[B], np.float32(0.6))) < BF16_LAYER_TOL
+            assert rel_l2(got_s, ref_real.forward(xs[B], np.float32(0.6))) < BF16_SCORE_TOL
+    want = sample(gpu_real, 777, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision="bf16", keep_state=True)
+    assert rel_l2(np.load(tmp_path / "xs.npy"), want.x_final.cpu().numpy()) < 1e-2

@@ -165,7 +165,7 @@ struct idm_model {
     float *w_head = nullptr;               // (F, C) float32
     void *wpack_f32[IDM_NCONV] = {};       // layers 1..9
     void *wpack_bf16[IDM_NCONV] = {};
-    void *wpack_m16[IDM_NCONV] = {};       // layers whose fused kernel has a 16x16x32-MFMA instance (conv6)
+    void *wpack_m16[IDM_NCONV] = {};       // layers whose fused kernel has a 16x16x32-MFMA instance
     void *wpack_fold[IDM_NCONV] = {};      // BatchNorm models: bf16 pack of W*scale (strip kernels)
     float *bias_fold[IDM_NCONV] = {};      // bias*scale + shift
     float *bias[IDM_NCONV] = {};
@@ -478,6 +478,7 @@ int forward_fused(idm_model *m, const Plan &p, const float *x, const float *tadd
     auto layer = [&](FusedArgs &a, int l1, int l2) {
         a.w1 = l1 == 0 ? m->w_first_pack : m->wpack_bf16[l1];
         a.w1_alt = m->wpack_m16[l1];
+        a.w2_alt = m->wpack_m16[l2];
         a.b1 = m->bias[l1];
         a.w2 = m->wpack_bf16[l2]; a.b2 = m->bias[l2];
     };
@@ -779,7 +780,7 @@ int idm_model_create(idm_model **out, int device, const idm_model_desc *d)
             std::vector<float> pf = pack_weights_f32(d->conv_w[i], cin[i], cout[i]);
             rc = upload(m, pb.data(), pb.size(), (uint16_t **)&m->wpack_bf16[i]);
             if (rc == IDM_OK) rc = upload(m, pf.data(), pf.size(), (float **)&m->wpack_f32[i]);
-            if (rc == IDM_OK && i == 6 && !m->bn) {
+            if (rc == IDM_OK && (i == 2 || i == 3 || i == 6 || i == 7) && !m->bn) {   // the layers on 16 x 16 maps at L = 32
                 std::vector<uint16_t> p16 = pack_weights_bf16_m16(d->conv_w[i], cin[i], cout[i]);
                 rc = upload(m, p16.data(), p16.size(), (uint16_t **)&m->wpack_m16[i]);
             }

@@ -303,7 +303,11 @@ struct ConvStage {
     // inter(integral_constant<int, st>) is called once in every superstep, in the same scheduling region as that
     // superstep's MFMAs: work that does not depend on this piece (another piece's epilogue) issues in their shadow.
     // An epi that takes a leading integral_constant<int, tile> is told which tile of the piece it is handed.
-    template <int N, class Epi, class Hook, class Inter = NoInter>
+    // UPPAR: parity of the piece's first window row in the half-resolution tile's row numbering (row + up_rb), when the
+    // caller knows it (0 / 1; -1 = unknown).  Two full-resolution rows share one half-resolution row, so of the N + 2
+    // fragments of an upsampled channel group only every other one differs: with the parity known those are read once
+    // and reused (N = 2: two or three LDS reads per superstep instead of four).
+    template <int N, int UPPAR = -1, class Epi, class Hook, class Inter = NoInter>
     DEVI void piece(int j, int sl, int cb, Epi &&epi, Hook &&hook, Inter &&inter = Inter{})
     {
         const int W = g.W, Wp2 = W + 2, Wh2 = (W >> 1) + 2;
@@ -365,6 +369,12 @@ struct ConvStage {
 #pragma unroll
             for (int i = 0; i < N + 2; ++i) {
                 if constexpr (cg < NCG_A) {
+#ifndef IDM_NO_UP_DEDUPE   // (comparison builds: read every fragment)
+                    if constexpr (UP && UPPAR >= 0) {
+                        // fragment i repeats fragment i - 1 when both full-resolution rows halve to the same row
+                        if (i > 0 && ((i + UPPAR) & 1)) { fr[st % FR][i] = fr[st % FR][i - 1]; continue; }
+                    }
+#endif
                     int addr;
                     if constexpr (UP) addr = a_up[i] + c_up[kx];
                     else addr = a_pl[i] + kx * SA;

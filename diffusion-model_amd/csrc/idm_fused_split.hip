@@ -7,6 +7,7 @@
 // pipe while plain ones do not (inline assembly is no alternative: the compiler does not see that it consumes a
 // transcendental's result and leaves out the wait state that needs).
 #include "idm_conv_stage.h"
+#include "idm_conv16.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -34,158 +35,6 @@ extern "C" int idm_debug_timeline3(long long *host)
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// conv6 of the L = 32 pyramid (16 x 16 map, input [UpSampling2D(conv5: 128 ch) | skip2: 64 ch], 64 couts) on
-// v_mfma_f32_16x16x32_bf16: D[16 couts][16 pixels] += W[16 couts][32 ch] * X[32 ch][16 pixels], one map row per MFMA.
-//
-// One wavefront computes what the 32x32x16 stage gives it: a 32-cout slice (two 16-cout halves) of eight rows, in two
-// groups of four vertically adjacent rows (j0 .. j0+3 and j0+8 .. j0+11).  A superstep is one (kx, 32-channel group):
-// its six weight fragments (3 ky x 2 cout halves, 1 KB each, from L2 through a register ring) and the six input rows
-// of each group feed 3 x 4 x 2 = 24 MFMAs per group.  The rows of the half-resolution tile repeat (full-resolution rows
-// 2m-1 and 2m read the same one), so a group reads four fragments of it per superstep, not six.
-// Operand lane maps: B fragment lane l = pixel l & 15, channels 8 (l >> 4) .. +7 of the group (16 bytes of the tile);
-// A fragment lane l = cout l & 15, the same channels (host-packed [tap][ch / 32][cout / 16][lane][8]);
-// D lane l = pixel l & 15, couts 4 (l >> 4) .. +3.  Tile positions are 2 C + 32 bytes apart: with that stride the
-// 16-lane groups of ds_read_b128, which here mix two 8-channel blocks of eight pixels each, touch every bank once.
-// Every address is fixed per wavefront for the whole launch.
-// ---------------------------------------------------------------------------------------------
-template <int WD>
-struct Conv6Mfma16 {
-    static constexpr int W = 16, CA = 128, CB = 64, COUT = 64, SA = CA * 2 + 32, SB = CB * 2 + 32, SM = COUT * 2 + 16;
-    static constexpr int NGA = CA / 32, NGB = CB / 32, NCG = NGA + NGB, NS = 3 * NCG, MT16 = COUT / 16;
-    static constexpr int PU = (W / 2 + 2) * SA, PB = (W + 2) * SB, PM = (W + 2) * SM;
-    static constexpr int WR = WD + 1;
-    static_assert(WD >= 1 && WD < NS, "weights run one or more supersteps ahead");
-
-    const char *ta, *tb;
-    char *dst0[2];                  // mid tile: first row of each row group, this lane's pixel and first cout
-    const float *bias;              // this lane's first cout of the slice
-    __amdgpu_buffer_rsrc_t wrsrc;
-    unsigned woff;
-    int ra[2][4], rb[2][6], cu[3];  // byte offsets: tile_a rows (4 distinct per group), tile_b rows, tile_a column per kx
-    bf16x8 wq[WR][3][2];
-
-    DEVI void setup(const char *tile_a, const char *tile_b, const float *c_bias, const void *w16, char *mid, int lane,
-                    int sl, int j0)
-    {
-        const int x = lane & 15, cb = lane >> 4;
-        ta = tile_a; tb = tile_b;
-        bias = c_bias + 32 * sl + 4 * cb;
-        wrsrc = make_rsrc(w16, 9u * (CA + CB) * COUT * 2u);
-        unsigned o = (unsigned)(lane * 16 + 2 * sl * 1024);
-        asm volatile("" : "+v"(o));     // (opaque: keeps the weight fetches from being hoisted out of the lattice loop)
-        woff = o;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            // output rows j0 + 8 g + n, n < 4; their taps read global rows j0 + 8 g - 1 .. + 4.  tile_b row = global row + 1,
-            // tile_a row = (global row >> 1) + 1; global rows -1 / 16 (half rows -1 / 8) are padding and share row 0.
-            const int g0 = j0 + 8 * g - 1;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int t = g0 + i + 1;
-                rb[g][i] = (t == W + 1 ? 0 : t) * PB + x * SB + cb * 16;
-            }
-            const int h0 = ((g0 + 2) >> 1);      // tile_a row of the group's first input row (g0 is odd)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int t = h0 + k;
-                ra[g][k] = (t == W / 2 + 1 ? 0 : t) * PU;
-            }
-            dst0[g] = mid + ((1 + j0 + 8 * g) * (W + 2) + x + 1) * SM + (32 * sl + 4 * cb) * 2;
-        }
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) cu[kx] = ((x + kx + 1) >> 1) * SA + cb * 16;
-    }
-
-    template <int S>
-    DEVI void issue_w()
-    {
-        constexpr int kx = S / NCG, cg = S % NCG;
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int hc = 0; hc < 2; ++hc) {
-                const unsigned k = (((ky * 3 + kx) * NCG + cg) * MT16 + hc) * 1024;
-                wq[S % WR][ky][hc] = buf_load16(wrsrc, woff + (k & 0xFFFu), k & ~0xFFFu);
-            }
-    }
-
-    DEVI void prologue()
-    {
-        static_for<0, WD>([&](auto S) { issue_w<decltype(S)::value>(); });
-    }
-
-    // fragment i (input row i of the group) of superstep S: index into the fragments read for that superstep
-    template <int S>
-    static constexpr int fidx(int i) { return (S % NCG) < NGA ? (i + 1) >> 1 : i; }
-    template <int S>
-    static constexpr int nfrag() { return (S % NCG) < NGA ? 4 : 6; }
-
-    template <int S>
-    DEVI void read_group(int g, bf16x8 (&f)[6]) const
-    {
-        constexpr int kx = S / NCG, cg = S % NCG;
-        if constexpr (cg < NGA) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) f[k] = *(const bf16x8 *)(ta + ra[g][k] + cu[kx] + cg * 64);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) f[i] = *(const bf16x8 *)(tb + rb[g][i] + kx * SB + (cg - NGA) * 64);
-        }
-    }
-
-    // one lattice: prologue() has been called since the last run(); the input tiles are complete
-    DEVI void run()
-    {
-        f32x4 acc[2][4][2];
-        {
-            const f32x4 k0 = *(const f32x4 *)bias, k1 = *(const f32x4 *)(bias + 16);
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) { acc[g][n][0] = k0; acc[g][n][1] = k1; }
-        }
-        bf16x8 f0[6], f1[6];
-        read_group<0>(0, f0);
-        static_for<0, NS>([&](auto SS) {
-            constexpr int S = decltype(SS)::value;
-            // pin the software pipeline (weights WD supersteps ahead, the second group's rows while the first computes,
-            // the next superstep's first rows while the second computes)
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (S + WD < NS) issue_w<S + WD>();
-            read_group<S>(1, f1);
-            __builtin_amdgcn_sched_barrier(0);   // (or the scheduler sinks the reads to just before their first use)
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-#pragma unroll
-                    for (int hc = 0; hc < 2; ++hc)
-                        acc[0][n][hc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[S % WR][ky][hc], f0[fidx<S>(n + ky)], acc[0][n][hc], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (S + 1 < NS) read_group<S + 1>(0, f0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-#pragma unroll
-                    for (int hc = 0; hc < 2; ++hc)
-                        acc[1][n][hc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[S % WR][ky][hc], f1[fidx<S>(n + ky)], acc[1][n][hc], 0, 0, 0);
-        });
-        // activation and store: this lane's four couts of one pixel per accumulator
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int hc = 0; hc < 2; ++hc) {
-                    const f32x4 v = acc[g][n][hc];
-                    *(bf16x4 *)(dst0[g] + n * PM + hc * 32) = pack4(silu1(v[0]), silu1(v[1]), silu1(v[2]), silu1(v[3]));
-                }
-    }
-};
-
-// ---------------------------------------------------------------------------------------------
 // fused_M3 (conv6 + conv7 on the whole 16x16 map of the L = 32 pyramid) with the tile copies on wavefronts of their own.
 //
 // The four-wavefront kernel runs one workgroup per CU (its LDS tiles take 125 KB), i.e. one wavefront per SIMD, so its
@@ -202,20 +51,20 @@ struct Conv6Mfma16 {
 // 36.9 KB of tiles and 1 KB of constants just fit the 160 KB of a CU.  Partition, epilogue arithmetic and results are
 // those of fused2_kernel.
 // ---------------------------------------------------------------------------------------------
-// MF16: conv6 runs on v_mfma_f32_16x16x32_bf16 (Conv6Mfma16 above) instead of the 32x32x16 stage: its input tiles then have
-// a 32-byte pad per position and share one all-zero row between the map's top and bottom padding (tile_a: 9 rows for global
-// half-resolution rows -1 .. 7, tile_b: 17 rows for global rows -1 .. 15); conv7, the mid tile and the staging tile are
-// unchanged.  Results differ from the 32x32x16 kernel by the summation order of conv6 only.
+// MF16: both convolutions run on v_mfma_f32_16x16x32_bf16 (ConvMfma16, idm_conv16.h) instead of the 32x32x16 stages: the
+// input tiles and the mid tile then have a 32-byte pad per position and share one all-zero row between the map's top and
+// bottom padding (tile_a: 9 rows, tile_b and mid: 17).  Results differ from the 32x32x16 kernel by summation order only.
 template <int NT1, int WD1, int NT2, int WD2, bool DEFER, bool MF16 = false>
 __global__ __launch_bounds__(512, 1) void fused_m3_split_kernel(FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int W = 16, H = 16, R = 16, CA = 128, CB = 64, C1 = 64, C2 = 64;
     constexpr int PADI = MF16 ? 32 : 16;
-    constexpr int SA = CA * 2 + PADI, SB = CB * 2 + PADI, SM = C1 * 2 + 16, SO = C2 * 2 + 16;
+    constexpr int SA = CA * 2 + PADI, SB = CB * 2 + PADI, SM = C1 * 2 + PADI, SO = C2 * 2 + 16;
     constexpr int ROWS_A = MF16 ? R / 2 + 1 : R / 2 + 2, ROWS_B = MF16 ? R + 1 : R + 4, G0_B = MF16 ? -1 : -2;
+    constexpr int ROWS_M = MF16 ? R + 1 : R + 2;
     constexpr int TILE_A = (ROWS_A * (W / 2 + 2) * SA + 15) & ~15, TILE_B = ROWS_B * (W + 2) * SB;
-    constexpr int IN = TILE_A + TILE_B, MID = (R + 2) * (W + 2) * SM, STAGE = R * W * SO;
+    constexpr int IN = TILE_A + TILE_B, MID = ROWS_M * (W + 2) * SM, STAGE = R * W * SO;
     static_assert(!(MF16 && DEFER), "the 16x16x32 instance finishes conv7's epilogue right after its loop");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool copier = wave >= 4;          // wave-uniform
@@ -228,39 +77,25 @@ __global__ __launch_bounds__(512, 1) void fused_m3_split_kernel(FusedArgs a)
     const float *c_b1 = cst, *c_b2 = cst + C1;
     for (int i = tid; i < C1; i += 512) cst[i] = a.b1[i];
     for (int i = tid; i < C2; i += 512) cst[C1 + i] = a.b2[i];
-    // the mid tile's halo columns and its two padding rows (above and below the map) are never written afterwards
-    clear_halo<C1, 512>(mid, W, R + 2, 0, 1, tid);
-    clear_halo<C1, 512>(mid, W, 0, R + 1, R + 2, tid);
+    // the mid tile's halo columns and its padding rows (above and below the map; MF16: one shared row) are never written afterwards
+    clear_halo<C1, 512, PADI>(mid, W, ROWS_M, 0, 1, tid);
+    if constexpr (!MF16) clear_halo<C1, 512, PADI>(mid, W, 0, R + 1, R + 2, tid);
     const int first = (int)blockIdx.x, step = (int)gridDim.x;
     const LaneGeo geo = make_geo(W, lane & 31);
 
     if constexpr (MF16) if (!copier) {
-        using Conv2 = ConvStage<C1, 0, false, C2, NT2, 1, WD2, false>;
-        Conv6Mfma16<WD1> c6;
-        Conv2 cs2;
-        const int sl = rw >> 1, j0 = (rw & 1) * 4;
+        ConvMfma16<CA, CB, C1, WD1, SM, true> c6;
+        ConvMfma16<0, C1, C2, WD2, SO, false> c7;
+        const int sl = rw >> 1, j0 = (rw & 1) * 4;     // the partition of the 32x32x16 kernel
         c6.setup(tile_a, tile_b, c_b1, a.w1_alt, mid, lane, sl, j0);
-        cs2.begin(mid, nullptr, c_b2, nullptr, geo, 0, R, (const bf16x8 *)a.w2, rw, lane, 0, 4, true);
-        cs2.set_weights((const bf16x8 *)a.w2, lane);
-        cs2.set_slice(sl);
-        auto epi2 = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *, int mt, int r, int x, bool valid) {
-            if (!valid) return;
-            char *dst = stage + __mul24(__mul24(r, W) + x, SO) + (mt * 32 + 4 * h) * 2;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                z = silu4(BIAS_IN_ACC ? z : z + kb[g]);
-                *(bf16x4 *)(dst + 16 * g) = pack4(z[0], z[1], z[2], z[3]);
-            }
-        };
-        auto nohook = [](int) {};
+        c7.setup(nullptr, mid, c_b2, a.w2_alt, stage, lane, sl, j0);
         if (first < nlat) c6.prologue();
         __syncthreads();                       // constants, halo, the first lattice's tiles
         for (int b = first; b < nlat; b += step) {
             c6.run();
-            cs2.prologue();
+            c7.prologue();
             __syncthreads();                   // B1
-            cs2.template piece<4>(j0, sl, 0, epi2, nohook);
+            c7.run();
             if (b + step < nlat) c6.prologue();
             __syncthreads();                   // B2
         }
@@ -428,15 +263,17 @@ hipError_t launch_m3_split(const FusedArgs &a, int64_t B, hipStream_t s)
 {
     // ISINGDIFF_M3_DEFER=0: conv7's epilogue right after its MFMA loop (comparison runs)
     static const bool defer = [] { const char *e = getenv("ISINGDIFF_M3_DEFER"); return !(e && e[0] == '0'); }();
-    // ISINGDIFF_M3_MFMA16=1: conv6 on v_mfma_f32_16x16x32_bf16 (same values up to summation order; read once per process)
-    static const bool mf16 = [] { const char *e = getenv("ISINGDIFF_M3_MFMA16"); return e && e[0] == '1'; }();
-    const bool use16 = mf16 && a.w1_alt != nullptr;
-    auto kernel = use16 ? fused_m3_split_kernel<4, IDM_M3_MFMA16_WD, 4, 3, false, true>
+    // conv6 and conv7 on v_mfma_f32_16x16x32_bf16 (the default: the same time for this kernel at a 0.2 GHz higher clock,
+    // i.e. less energy, which the other kernels of the step get back as clock: +1.2 ... 1.9 % for the whole job);
+    // ISINGDIFF_M3_MFMA16=0 selects the 32x32x16 stages (same values up to summation order; read once per process)
+    static const bool mf16 = [] { const char *e = getenv("ISINGDIFF_M3_MFMA16"); return !(e && e[0] == '0'); }();
+    const bool use16 = mf16 && a.w1_alt != nullptr && a.w2_alt != nullptr;
+    auto kernel = use16 ? fused_m3_split_kernel<4, IDM_M3_MFMA16_WD, 4, IDM_M3_MFMA16_WD, false, true>
                   : defer ? fused_m3_split_kernel<4, 2, 4, 3, true> : fused_m3_split_kernel<4, 2, 4, 3, false>;
     constexpr int tile_a = ((16 / 2 + 2) * (16 / 2 + 2) * 272 + 15) & ~15, tile_b = 20 * 18 * 144, mid = 18 * 18 * 144,
                   stage = 16 * 16 * 144;
     constexpr int lds32 = tile_a + tile_b + mid + stage + (64 + 64) * 4;
-    constexpr int lds16 = 9 * 10 * 288 + 17 * 18 * 160 + mid + stage + (64 + 64) * 4;
+    constexpr int lds16 = 9 * 10 * 288 + 17 * 18 * 160 + 17 * 18 * 160 + stage + (64 + 64) * 4;
     static_assert(lds32 <= 160 * 1024 && lds16 <= 160 * 1024, "the tiles must fit a CU");
     const int lds = use16 ? lds16 : lds32;
     static thread_local struct { bool configured = false; int cus = 0; } all_st[IDM_MAX_DEVICES][2];
@@ -618,8 +455,11 @@ __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
                     }
                 };
                 auto inter = [&](auto ST) { chunks_of(ST, std::integral_constant<int, Conv1::NS>{}, ride); };
+                // (the parity of the piece's first window row is known per band: the half-resolution tile's fragments are
+                // then read once per half-resolution row)
                 if (cs1.f1 - cs1.f == 3) cs1.template piece<3>(cs1.f, 0, 0, sink, nohook, inter);
-                else cs1.template piece<2>(cs1.f, 0, 0, sink, nohook, inter);
+                else if ((rlo + cs1.f) & 1) cs1.template piece<2, 1>(cs1.f, 0, 0, sink, nohook, inter);
+                else cs1.template piece<2, 0>(cs1.f, 0, 0, sink, nohook, inter);
                 d8 = nd;
             } else {
                 flush();

@@ -107,9 +107,10 @@ struct FusedArgs {
     const void *in_a;  // PLAIN: (B,H,W,CA); UPCAT: (B,H/2,W/2,CA); FIRST: x float32 (B,Hx,Wx)
     const void *in_b;  // UPCAT: (B,H,W,CB)
     const void *w1;
-    const void *w1_alt;        // FK_M3: conv6's weights packed for v_mfma_f32_16x16x32_bf16 ([tap][ch/32][cout/16][lane][8]), or null
+    const void *w1_alt;        // the first convolution's weights packed for v_mfma_f32_16x16x32_bf16 ([tap][ch/32][cout/16][lane][8]), or null
     const float *b1, *tadd1;   // bias; per-channel add after the activation (FK_M2 only)
     const void *w2;
+    const void *w2_alt;        // the same for the pair's second convolution
     const float *b2;
     void *out;         // STORE*: (B,H,W,C2) bf16
     void *out_pool;    // STORE_POOL: (B,H/2,W/2,C2) bf16

@@ -461,27 +461,31 @@ def test_copy_wavefront_kernels_are_bit_identical_to_the_four_wavefront_ones(gpu
         "for B in (1, 5, 777, 2049):\n"
         "    r = sample(m, B, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision='bf16', keep_state=True)\n"
         "    np.save(os.path.join(sys.argv[1], f'{sys.argv[2]}{B}.npy'), r.x_final.cpu().numpy())\n")
-    switches = ("ISINGDIFF_M3_SPLIT", "ISINGDIFF_B_SPLIT", "ISINGDIFF_M3_DEFER", "ISINGDIFF_B_DEFER")
+    switches = ("ISINGDIFF_M3_SPLIT", "ISINGDIFF_B_SPLIT", "ISINGDIFF_M3_DEFER", "ISINGDIFF_B_DEFER", "ISINGDIFF_M3_MFMA16")
     assert not any(k in os.environ for k in switches)
-    variants = (("m", {"ISINGDIFF_M3_SPLIT": "0"}), ("b", {"ISINGDIFF_B_SPLIT": "0"}),
+    # (every variant, and the base it is compared with, runs conv6 + conv7 on the 32x32x16 MFMA: the default 16x16x32
+    # instance sums in another order and is held to a tolerance by the test below)
+    variants = (("base", {}), ("m", {"ISINGDIFF_M3_SPLIT": "0"}), ("b", {"ISINGDIFF_B_SPLIT": "0"}),
                 ("d", {"ISINGDIFF_M3_DEFER": "0", "ISINGDIFF_B_DEFER": "0"}))
     for tag, env in variants:
-        subprocess.run([sys.executable, "-c", code, str(tmp_path), tag], check=True, env=dict(os.environ, **env), timeout=240)
+        subprocess.run([sys.executable, "-c", code, str(tmp_path), tag], check=True,
+                       env=dict(os.environ, ISINGDIFF_M3_MFMA16="0", **env), timeout=240)
+    variants = variants[1:]
     for B in (1, 5, 777, 2049):
-        want = sample(gpu_real, B, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision="bf16", keep_state=True)
-        want = want.x_final.cpu().numpy()
+        want = np.load(tmp_path / f"base{B}.npy")
         for tag, _ in variants:
             got = np.load(tmp_path / f"{tag}{B}.npy")
             assert np.isfinite(got).all()
             assert np.array_equal(got, want), (tag, B)
 
 
-def test_conv6_on_the_16x16x32_mfma_matches_the_32x32x16_kernel(gpu_real, real_spec, ref_real, tmp_path):
-    """ISINGDIFF_M3_MFMA16=1 runs conv6 of the L=32 bf16 sampler on v_mfma_f32_16x16x32_bf16 (other operand lane maps,
-    input tiles with a 32-byte pad and a shared zero row, weights packed per 16 couts x 32 channels).  Same products,
-    another summation order: conv7's map within 4e-3 relative L2 of the default kernel's (bf16 rounding of conv6's
-    output can move by an ulp), the score within the bf16 tolerances of the oracle, for batches that leave workgroups
-    with zero, one and several lattices; three sampler steps stay within 1e-2.  (The switch is read once per process.)"""
+def test_conv6_conv7_on_the_16x16x32_mfma_match_the_32x32x16_kernel(gpu_real, real_spec, ref_real, tmp_path):
+    """By default conv6 and conv7 of the L=32 bf16 sampler run on v_mfma_f32_16x16x32_bf16 (other operand lane maps,
+    tiles with a 32-byte pad and a shared zero row, weights packed per 16 couts x 32 channels); ISINGDIFF_M3_MFMA16=0
+    selects the 32x32x16 stages.  Same products, another summation order: conv7's map within 4e-3 relative L2 of each
+    other (bf16 rounding of conv6's output can move by an ulp), the default's score within the bf16 tolerances of the
+    oracle, for batches that leave workgroups with zero, one and several lattices; three sampler steps stay within
+    1e-2.  (The switch is read once per process.)"""
     import os, subprocess, sys
     from oracle import ref_cpu
     from isingdiff.sampler import sample, beta_schedule
@@ -504,7 +508,7 @@ def test_conv6_on_the_16x16x32_mfma_matches_the_32x32x16_kernel(gpu_real, real_s
         xs[B] = ising_like(rng, B, 32, 32, 600)
         np.save(tmp_path / f"x{B}.npy", xs[B])
     assert "ISINGDIFF_M3_MFMA16" not in os.environ
-    subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, env=dict(os.environ, ISINGDIFF_M3_MFMA16="1"), timeout=240)
+    subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, env=dict(os.environ, ISINGDIFF_M3_MFMA16="0"), timeout=240)
     refq = ref_cpu.RefModel(real_spec, quant_bf16=True)
     for B in (1, 5, 300):
         want_s, want_t = gpu_real.forward_taps(xs[B], np.float32(0.6), precision="bf16")
@@ -513,7 +517,8 @@ def test_conv6_on_the_16x16x32_mfma_matches_the_32x32x16_kernel(gpu_real, real_s
         assert rel_l2(got_t, want_t[7].cpu().numpy()) < 4e-3, B
         assert rel_l2(got_s, want_s.cpu().numpy()) < 1e-2, B
         if B <= 5:
-            assert rel_l2(got_s, refq.forward(xs[B], np.float32(0.6))) < BF16_LAYER_TOL
-            assert rel_l2(got_s, ref_real.forward(xs[B], np.float32(0.6))) < BF16_SCORE_TOL
+            for s_ in (got_s, want_s.cpu().numpy()):
+                assert rel_l2(s_, refq.forward(xs[B], np.float32(0.6))) < BF16_LAYER_TOL
+                assert rel_l2(s_, ref_real.forward(xs[B], np.float32(0.6))) < BF16_SCORE_TOL
     want = sample(gpu_real, 777, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision="bf16", keep_state=True)
     assert rel_l2(np.load(tmp_path / "xs.npy"), want.x_final.cpu().numpy()) < 1e-2

@@ -167,6 +167,9 @@ struct idm_model {
     void *wpack_bf16[IDM_NCONV] = {};
     void *wpack_m16[IDM_NCONV] = {};       // layers whose fused kernel has a 16x16x32-MFMA instance
     void *wpack_fold[IDM_NCONV] = {};      // BatchNorm models: bf16 pack of W*scale (strip kernels)
+    void *wpack_tr[IDM_NCONV] = {};        // two-channel models: the strip kernels' pack with the 3x3 taps transposed
+    float *w_first_tr = nullptr;           // ... and layer 0's (9, C, F) kernel likewise
+    bool use_transpose = true;             // two-channel models: process the map transposed when that fills the MFMA lanes
     float *bias_fold[IDM_NCONV] = {};      // bias*scale + shift
     float *bias[IDM_NCONV] = {};
     float *scale[IDM_NCONV] = {};
@@ -206,6 +209,7 @@ struct Plan {
     bool fused;          // bf16 band kernels usable for this shape
     int R[5];            // band rows per fused kernel
     bool layers;         // bf16, 2-channel / BatchNorm model: layers 1..9 run as strip kernels (BatchNorm folded)
+    bool tr;             // ... on the transposed map: H, W, Hp, Wp are then the transposed (processing) sizes
     bool lpair[5];       // ... except these pairs (FK_M1, FK_M2, FK_M3), which run as fused band kernels with R[] rows
     bool strip[5];       // this pair of layers runs as single-convolution strip kernels instead
     int sR[SK_COUNT], sWS[SK_COUNT];   // band rows / strip columns of the strip kernels
@@ -248,10 +252,11 @@ int pick_strip_rows(int kind, int H, int W, int *WS)
     // strips tile the width exactly; pooled / upsampled layers need an even strip, the update float4 quads
     const bool even = kind == SK_CONV1 || kind == SK_CONV3 || kind == SK_CONV6 || kind == SK_CONV8;
     if (W % ws != 0 || (even && (ws & 1)) || (kind == SK_CONV9 && (ws & 3))) return 0;
-    const int cand[4] = {16, 8, 4, 2};
-    for (int i = 0; i < 4; ++i) {
+    const int cand[5] = {16, 10, 8, 4, 2};   // (10: the 20-row top level of the transposed spectral map)
+    for (int i = 0; i < 5; ++i) {
         const int R = cand[i];
         if (R > H || H % R != 0) continue;
+        if (R == 10 && !(ws == 32 && (kind == SK_CONV1 || kind == SK_CONV8 || kind == SK_CONV9H2))) continue;
         int in = 0, st = 0, cs = 0;
         strip_lds_bytes(kind, R, ws, &in, &st, &cs);
         if (in + st + cs <= 78 * 1024 && strip_fits(kind, R, ws)) return R;
@@ -259,9 +264,23 @@ int pick_strip_rows(int kind, int H, int W, int *WS)
     return 0;
 }
 
-Plan make_plan(const idm_model *m, int H, int W, int precision)
+// allow_tr: the caller does not ask for the per-layer maps (which would come out transposed).
+Plan make_plan(const idm_model *m, int H, int W, int precision, bool allow_tr = true)
 {
     Plan p;
+    p.tr = false;
+    {
+        // The spectral state of an L x L lattice is L x (L/2 + 1): at L = 32 its padded top level is 32 rows x 20 columns, and
+        // a 32-pixel MFMA tile holds one 20-pixel row.  A 3x3 "same" convolution, 2x2 pooling, nearest upsampling and the
+        // concatenation all commute with transposition (the kernel's taps transposed), so the whole UNet can run on the
+        // transposed map, 20 rows x 32 columns, where every MFMA lane is a pixel.
+        const int hp = H + (4 - H % 4) % 4, wp = W + (4 - W % 4) % 4;
+        if (allow_tr && precision == IDM_BF16 && m->use_fused && m->use_transpose && m->C == 2 && m->w_first_tr &&
+            hp % 32 == 0 && wp % 32 != 0 && wp < hp) {
+            p.tr = true;
+            std::swap(H, W);
+        }
+    }
     p.H = H; p.W = W;
     p.Hp = H + (4 - H % 4) % 4;
     p.Wp = W + (4 - W % 4) % 4;
@@ -297,19 +316,27 @@ Plan make_plan(const idm_model *m, int H, int W, int precision)
         const int hh[3] = {p.Hp, p.Hp / 2, p.Hp / 4}, ww[3] = {p.Wp, p.Wp / 2, p.Wp / 4};
         const int lvl[SK_COUNT] = {0, 1, 1, 2, 2, 1, 1, 0, 0, 0, 0};
         p.layers = true;
-        for (int sk = SK_CONV1; sk < SK_COUNT; ++sk) {
-            if (sk == SK_CONV9) continue;
-            p.sR[sk] = pick_strip_rows(sk, hh[lvl[sk]], ww[lvl[sk]], &p.sWS[sk]);
-            if (p.sR[sk] == 0) p.layers = false;
-        }
+        for (int sk = SK_CONV1; sk < SK_COUNT; ++sk)
+            p.sR[sk] = sk == SK_CONV9 ? 0 : pick_strip_rows(sk, hh[lvl[sk]], ww[lvl[sk]], &p.sWS[sk]);
         // the three inner pairs have the real-space model's shapes: fused band kernels where a band of at least 8 rows
         // (or the whole map) fits
         const int lv[5] = {0, 1, 2, 1, 0};
         for (int k = FK_M1; k <= FK_M3; ++k) {
-            p.R[k] = p.layers ? pick_band_rows(k, hh[lv[k]], ww[lv[k]]) : 0;
+            p.R[k] = pick_band_rows(k, hh[lv[k]], ww[lv[k]]);
             p.lpair[k] = p.R[k] > 0 && (p.R[k] >= 8 || p.R[k] >= hh[lv[k]]);
         }
+        // Every layer needs its strip kernel (a caller that asks for the per-layer maps gets the strip launches) - except,
+        // on the transposed map, where nobody can ask for them, the layers of a pair that runs fused and the stored conv9.
+        const int pair_of[SK_COUNT] = {0, FK_M1, FK_M1, FK_M2, FK_M2, FK_M3, FK_M3, 0, 0, 0, 0};
+        for (int sk = SK_CONV1; sk < SK_COUNT; ++sk) {
+            if (sk == SK_CONV9) continue;
+            const bool spared = p.tr && ((pair_of[sk] && p.lpair[pair_of[sk]]) || sk == SK_CONV9S);
+            if (p.sR[sk] == 0 && !spared) p.layers = false;
+        }
+        if (!p.layers)
+            for (int k = FK_M1; k <= FK_M3; ++k) { p.R[k] = 0; p.lpair[k] = false; }
     }
+    if (p.tr && !p.layers) return make_plan(m, W, H, precision, false);   // (only the strip schedule has transposed weights)
     // Workspace: one buffer per kind, sized for what the selected schedule stores in it.  The fused schedule
     // keeps only the maps that cross a kernel boundary (skip1 and its pool, skip2 and its pool, conv5, conv7:
     // 172 KB per lattice at L = 32 in bf16), plus one intermediate per pair of layers that runs as strips.
@@ -577,7 +604,7 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
 
     const double npx = (double)Bc * Hp * Wp;
     timed(m, "conv_first", 2.0 * 9 * m->C * F * npx, (double)Bc * p.H * p.W * m->C * 4 + npx * F * p.es, s, [&] {
-        if (bf) launch_conv_first_bf16(x, Bc, p.H, p.W, Hp, Wp, m->C, m->w_first, m->bias[0], m->scale[0], m->shift[0], a0, s);
+        if (bf) launch_conv_first_bf16(x, Bc, p.H, p.W, Hp, Wp, m->C, p.tr ? m->w_first_tr : m->w_first, m->bias[0], m->scale[0], m->shift[0], a0, s, p.tr);
         else launch_conv_first(x, Bc, p.H, p.W, Hp, Wp, m->C, m->w_first, m->bias[0], m->scale[0], m->shift[0], a0, F, false, s);
     });
 
@@ -604,11 +631,11 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
         auto strip = [&](int sk, int l, const void *in_a, const void *in_b, void *out, void *out_pool, int H, int W) {
             if (rc != IDM_OK) return;
             StripArgs a = {};
-            if (sk == SK_CONV9H2) { a.w_head = m->w_head; a.b_head = m->bias[10]; a.score_out = score; }
+            if (sk == SK_CONV9H2) { a.w_head = m->w_head; a.b_head = m->bias[10]; a.score_out = score; a.transpose_out = p.tr ? 1 : 0; }
             a.H = H; a.W = W; a.R = p.sR[sk]; a.WS = p.sWS[sk]; a.nbands = H / a.R; a.nstrips = W / a.WS;
             a.Hx = p.H; a.Wx = p.W; a.B = Bc;
             a.in_a = in_a; a.in_b = in_b;
-            a.w = m->bn ? m->wpack_fold[l] : m->wpack_bf16[l];
+            a.w = p.tr ? m->wpack_tr[l] : m->bn ? m->wpack_fold[l] : m->wpack_bf16[l];
             a.bias = m->bn ? m->bias_fold[l] : m->bias[l];
             a.tadd = l == 4 ? tadd : nullptr;
             a.out = out; a.out_pool = out_pool;
@@ -625,9 +652,9 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
         auto pair = [&](int kind, int l1, const void *in_a, const void *in_b, void *out, void *out_pool, int H, int W) {
             if (rc != IDM_OK) return;
             FusedArgs a = {};
-            a.w1 = m->bn ? m->wpack_fold[l1] : m->wpack_bf16[l1];
+            a.w1 = p.tr ? m->wpack_tr[l1] : m->bn ? m->wpack_fold[l1] : m->wpack_bf16[l1];
             a.b1 = m->bn ? m->bias_fold[l1] : m->bias[l1];
-            a.w2 = m->bn ? m->wpack_fold[l1 + 1] : m->wpack_bf16[l1 + 1];
+            a.w2 = p.tr ? m->wpack_tr[l1 + 1] : m->bn ? m->wpack_fold[l1 + 1] : m->wpack_bf16[l1 + 1];
             a.b2 = m->bn ? m->bias_fold[l1 + 1] : m->bias[l1 + 1];
             a.tadd1 = l1 == 4 ? tadd : nullptr;
             a.in_a = in_a; a.in_b = in_b; a.out = out; a.out_pool = out_pool;
@@ -669,6 +696,7 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
             timed(m, "head", 2.0 * F * m->C * Bc * p.H * p.W, (double)Bc * p.H * p.W * (F * 2 + m->C * 4), s,
                   [&] { launch_head_bf16(a9, Bc, p.H, p.W, Hp, Wp, F, m->C, m->w_head, m->bias[10], score, s); });
     } else {
+    if (p.tr) return fail(IDM_ERR_HIP, "internal: transposed plan without the strip schedule");
     conv(1, a0, nullptr, F, 0, Hp, Wp, CONV_PLAIN, s1, nullptr, false);
     conv(2, s1, nullptr, F, 0, Hp / 2, Wp / 2, CONV_POOL, a2, nullptr, false);
     conv(3, a2, nullptr, 2 * F, 0, Hp / 2, Wp / 2, CONV_PLAIN, s2, nullptr, false);
@@ -769,6 +797,14 @@ int idm_model_create(idm_model **out, int device, const idm_model_desc *d)
         if (rc != IDM_OK) break;
         if (i == 0) {
             rc = upload(m, d->conv_w[0], (size_t)9 * c * f, &m->w_first);
+            if (rc == IDM_OK && c == 2) {
+                std::vector<float> wt((size_t)9 * c * f);
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx)
+                        std::copy(d->conv_w[0] + (size_t)(kx * 3 + ky) * c * f, d->conv_w[0] + (size_t)(kx * 3 + ky + 1) * c * f,
+                                  wt.begin() + (size_t)(ky * 3 + kx) * c * f);
+                rc = upload(m, wt.data(), wt.size(), &m->w_first_tr);
+            }
             if (rc == IDM_OK && c == 1) {
                 std::vector<uint16_t> pk = pack_first_bf16(d->conv_w[0], f);
                 rc = upload(m, pk.data(), pk.size(), (uint16_t **)&m->w_first_pack);
@@ -784,14 +820,26 @@ int idm_model_create(idm_model **out, int device, const idm_model_desc *d)
                 std::vector<uint16_t> p16 = pack_weights_bf16_m16(d->conv_w[i], cin[i], cout[i]);
                 rc = upload(m, p16.data(), p16.size(), (uint16_t **)&m->wpack_m16[i]);
             }
+            std::vector<float> wf(d->conv_w[i], d->conv_w[i] + (size_t)9 * cin[i] * cout[i]);   // what the strip kernels multiply by
             if (rc == IDM_OK && m->bn) {
                 // inference BatchNorm folded into the convolution: (W x + b)*s + h = (W*s) x + (b*s + h)
-                std::vector<float> wf((size_t)9 * cin[i] * cout[i]), bf_(cout[i]);
+                std::vector<float> bf_(cout[i]);
                 for (size_t k = 0; k < wf.size(); ++k) wf[k] = d->conv_w[i][k] * d->bn_scale[i][k % cout[i]];
                 for (int k = 0; k < cout[i]; ++k) bf_[k] = d->conv_b[i][k] * d->bn_scale[i][k] + d->bn_shift[i][k];
                 std::vector<uint16_t> pfold = pack_weights_bf16(wf.data(), cin[i], cout[i]);
                 rc = upload(m, pfold.data(), pfold.size(), (uint16_t **)&m->wpack_fold[i]);
                 if (rc == IDM_OK) rc = upload(m, bf_.data(), bf_.size(), &m->bias_fold[i]);
+            }
+            if (rc == IDM_OK && c == 2) {
+                // the same kernel with its taps transposed, (ky, kx) -> (kx, ky): the convolution of the transposed map
+                const size_t per_tap = (size_t)cin[i] * cout[i];
+                std::vector<float> wt(wf.size());
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx)
+                        std::copy(wf.begin() + (kx * 3 + ky) * per_tap, wf.begin() + (kx * 3 + ky + 1) * per_tap,
+                                  wt.begin() + (ky * 3 + kx) * per_tap);
+                std::vector<uint16_t> ptr_ = pack_weights_bf16(wt.data(), cin[i], cout[i]);
+                rc = upload(m, ptr_.data(), ptr_.size(), (uint16_t **)&m->wpack_tr[i]);
             }
         }
     }
@@ -850,7 +898,7 @@ int idm_forward_taps(idm_model *m, const float *x_dev, float t_norm, float *scor
     if (!x_dev || !score_dev) return fail(IDM_ERR_INVALID, "null tensor");
     HIPCHK(hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
-    const Plan p = make_plan(m, H, W, precision);
+    const Plan p = make_plan(m, H, W, precision, taps_dev == nullptr);
     const int64_t chunk = auto_chunk(p, B);
     rc = ensure_ws(m, p.per_lattice * (size_t)chunk);
     if (rc != IDM_OK) return rc;
@@ -1065,6 +1113,7 @@ int idm_set_option(idm_model *m, const char *name, int value)
     if (!m || !name) return fail(IDM_ERR_INVALID, "null argument");
     if (!strcmp(name, "fused")) { m->use_fused = value != 0; return IDM_OK; }
     if (!strcmp(name, "strip_below_rows")) { m->strip_below_rows = value; return IDM_OK; }
+    if (!strcmp(name, "transpose")) { m->use_transpose = value != 0; return IDM_OK; }
     return fail(IDM_ERR_INVALID, std::string("unknown option ") + name);
 }
 

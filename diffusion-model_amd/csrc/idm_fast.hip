@@ -124,8 +124,10 @@ void launch_conv_bf16(const ConvArgs &a, hipStream_t s)
 __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__restrict__ x, int64_t B, int H, int W, int Hp, int Wp,
                                                               int C, const float *__restrict__ w, const float *__restrict__ bias,
                                                               const float *__restrict__ scale, const float *__restrict__ shift,
-                                                              __bf16 *__restrict__ out)
+                                                              __bf16 *__restrict__ out, int transposed)
 {
+    // transposed: the map is processed with rows and columns exchanged - x is stored (B, W, H, C), and the caller passes
+    // the kernel with its taps transposed - so that the output is the transposed map of the layer
     __shared__ __attribute__((aligned(16))) float ws[9 * 2 * 32];
     __shared__ __attribute__((aligned(16))) float bs[3 * 32];
     for (int i = threadIdx.x; i < 9 * C * 32; i += 256) ws[i] = w[i];
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
         const int yy = yo + tap / 3 - 1, xx = xo + tap % 3 - 1;
         if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;   // outside the map, or in its zero padding
         for (int c = 0; c < C; ++c) {
-            const float v = x[((b * H + yy) * W + xx) * C + c];
+            const float v = transposed ? x[((b * W + xx) * H + yy) * C + c] : x[((b * H + yy) * W + xx) * C + c];
             const float *wr = ws + (tap * C + c) * 32;
 #pragma unroll
             for (int f = 0; f < 32; ++f) acc[f] = fmaf(v, wr[f], acc[f]);
@@ -165,9 +167,9 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
 }
 
 void launch_conv_first_bf16(const float *x, int64_t B, int H, int W, int Hp, int Wp, int C, const float *w, const float *bias,
-                            const float *scale, const float *shift, void *out, hipStream_t s)
+                            const float *scale, const float *shift, void *out, hipStream_t s, bool transposed)
 {
     const unsigned grid = (unsigned)((B * Hp * Wp + 255) / 256);
     hipLaunchKernelGGL(conv_first_bf16_kernel, dim3(grid), dim3(256), 0, s, x, B, H, W, Hp, Wp, C, w, bias, scale, shift,
-                       (__bf16 *)out);
+                       (__bf16 *)out, transposed ? 1 : 0);
 }

@@ -62,7 +62,7 @@ struct PhiloxArgs {
 void launch_conv_f32(const ConvArgs &a, hipStream_t s);
 // bf16 output, one thread per pixel and 8 channels (idm_fast.hip)
 void launch_conv_first_bf16(const float *x, int64_t B, int H, int W, int Hp, int Wp, int C, const float *w, const float *bias,
-                            const float *scale, const float *shift, void *out, hipStream_t s);
+                            const float *scale, const float *shift, void *out, hipStream_t s, bool transposed = false);
 void launch_conv_first(const float *x, int64_t B, int H, int W, int Hp, int Wp, int C, const float *w,
                        const float *bias, const float *scale, const float *shift, void *out, int F,
                        bool out_bf16, hipStream_t s);
@@ -154,7 +154,8 @@ struct StripArgs {
     void *out_pool;    // POOL: (B,H/2,W/2,COUT) bf16
     const float *w_head, *b_head;
     float *x;
-    float *score_out;  // HEAD: (B,Hx,Wx); two-channel head: (B,Hx,Wx,2)
+    float *score_out;  // HEAD: (B,Hx,Wx); two-channel head: (B,Hx,Wx,2), or (B,Wx,Hx,2) when transpose_out
+    int transpose_out; // two-channel head: the map is processed transposed, the score leaves in the caller's layout
     const float *noise;
     float c1, beta, sd;
     int add_noise, do_update;

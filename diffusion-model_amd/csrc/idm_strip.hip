@@ -260,11 +260,19 @@ __global__ __launch_bounds__(WG, OCC) void strip_kernel(StripArgs a)
             pf_load(wg_next);
             __syncthreads();
             const int rowsx = min(rows, a.Hx - y0), colsx = min(WS, a.Wx - x0);
-            if (rowsx > 0 && colsx > 0) {
+            if (rowsx > 0 && colsx > 0 && !a.transpose_out) {
                 float *sg = a.score_out + (((int64_t)b * a.Hx + y0) * a.Wx + x0) * 2;
                 for (int i = tid; i < rowsx * colsx; i += WG) {
                     const int r = i / colsx, xc = i - r * colsx;
                     *(f32x2 *)(sg + ((int64_t)r * a.Wx + xc) * 2) = *(const f32x2 *)(score_s + (r * WS + xc) * 2);
+                }
+            } else if (rowsx > 0 && colsx > 0) {
+                // the caller's tensor is (B, Wx, Hx, 2): element (row y0 + r, column x0 + xc) of this map is its
+                // (x0 + xc, y0 + r); consecutive threads walk r, which is contiguous there
+                float *sg = a.score_out + (((int64_t)b * a.Wx + x0) * a.Hx + y0) * 2;
+                for (int i = tid; i < rowsx * colsx; i += WG) {
+                    const int xc = i / rowsx, r = i - xc * rowsx;
+                    *(f32x2 *)(sg + ((int64_t)xc * a.Hx + r) * 2) = *(const f32x2 *)(score_s + (r * WS + xc) * 2);
                 }
             }
         } else {
@@ -368,11 +376,18 @@ inline const TallKind &tall_of(int kind, int WS)
 {
     return WS == 32 ? kTall[kind] : WS == 16 && kind == SK_CONV5 ? kTall16Conv5 : kTallNarrow[kind];
 }
+// 10-row bands of 32-column strips (the spectral model's top level processed transposed: 20 rows x 32 columns) run on
+// the instances of the narrow strips, which take band height and strip width at run time and hold enough prefetch registers.
+inline bool is_ten_row(int kind, int R, int WS)
+{
+    return WS == 32 && R == 10 && (kind == SK_CONV1 || kind == SK_CONV8 || kind == SK_CONV9H2);
+}
 inline bool is_tall(int kind, int R, int WS)
 {
+    if (is_ten_row(kind, R, WS)) return true;
     return (WS >= 17 || (WS == 16 && kind == SK_CONV5)) && R > 0 && R == tall_of(kind, WS).rows;
 }
-inline bool is_alias(int kind, int R, int WS) { return is_tall(kind, R, WS) && tall_of(kind, WS).alias; }
+inline bool is_alias(int kind, int R, int WS) { return !is_ten_row(kind, R, WS) && is_tall(kind, R, WS) && tall_of(kind, WS).alias; }
 
 struct StripLaunch {
     bool configured = false;
@@ -430,7 +445,10 @@ bool strip_fits(int kind, int R, int WS)
 {
     const StripKind &k = kStrip[kind];
     int npa = k.npa, npb = k.npb;
-    if (is_tall(kind, R, WS)) {
+    if (is_ten_row(kind, R, WS)) {
+        npa = kTallNarrow[kind].npa;
+        npb = kTallNarrow[kind].npb;
+    } else if (is_tall(kind, R, WS)) {
         npa = tall_of(kind, WS).npa;
         npb = tall_of(kind, WS).npb;
     }
@@ -453,7 +471,7 @@ hipError_t launch_strip(int kind, const StripArgs &a, hipStream_t s)
     const int slot = idm_device_slot();
     if (slot < 0) return hipErrorInvalidDevice;
     StripLaunch *st = all_st[slot];
-    if (is_tall(kind, a.R, a.WS) && a.WS < 32) {
+    if (is_tall(kind, a.R, a.WS) && (a.WS < 32 || is_ten_row(kind, a.R, a.WS))) {
         constexpr int T = 2 * SK_COUNT + 6;
         switch (kind) {
         case SK_CONV5: return launch_strip_one(st[T + 3], strip_kernel<128, 0, false, 128, SE_STORE, false, 4, 1, IDM_STRIP_WD, kTall16Conv5.npa, 0, 2, 16, 8, true>, a, s);

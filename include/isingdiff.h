@@ -223,7 +223,11 @@ int idm_allreduce_i64(idm_comm *c, int64_t *const *per_device_bufs, size_t count
 int idm_comm_destroy(idm_comm *c);
 
 /* Tuning switches (no counterpart in the reference).  "fused" (default 1): bf16 forward uses
- * the fused two-convolution band kernels when the shape fits; 0 forces one kernel per layer. */
+ * the fused two-convolution band kernels when the shape fits; 0 forces one kernel per layer.
+ * "strip_below_rows" (default 8): fused bands shorter than this run as single-convolution strip kernels.
+ * "transpose" (default 1): two-channel (spectral) models in bf16 process the map transposed when its padded height
+ * is a multiple of 32 and its width is not (the 32 x 17 spectrum of a 32 x 32 lattice), so that every MFMA lane holds a
+ * pixel; inputs and outputs keep their layout. */
 int idm_set_option(idm_model *m, const char *name, int value);
 
 /* Per-kernel timing for roofline accounting (no counterpart in the reference).  Between

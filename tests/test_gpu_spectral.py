@@ -60,6 +60,40 @@ def test_fft_unet_forward_bf16_tolerance(gpu_fft, ref_fft, fft_spec):
     assert rel_l2(got, want) < 2e-2
 
 
+@pytest.mark.parametrize("B", [1, 3, 260])
+def test_fft_unet_bf16_on_the_transposed_map(gpu_fft, ref_fft, fft_spec, B):
+    """At L = 32 the spectrum is 32 x 17 (padded 32 x 20): the bf16 schedule processes it transposed (20 rows x 32
+    columns, transposed 3x3 taps, state and score in the caller's layout) so that every MFMA lane is a pixel.  Against
+    the oracle within the bf16 tolerances, against the untransposed schedule (option "transpose" = 0) within 5e-3
+    (another summation order), also through three sampler steps."""
+    from oracle import ref_cpu
+    from isingdiff.sampler import beta_schedule, diffusion_backward
+    x = spectra(np.random.default_rng(40 + B), B, 32, 700)
+    tn = np.float32(0.7)
+    got = gpu_fft([x, tn], precision="bf16")
+    try:
+        gpu_fft.set_option("transpose", 0)
+        plain = gpu_fft([x, tn], precision="bf16")
+    finally:
+        gpu_fft.set_option("transpose", 1)
+    assert np.isfinite(got).all() and got.shape == x.shape
+    assert rel_l2(got, plain) < 5e-3
+    assert not np.array_equal(got, plain)            # (the two schedules do differ: the switch is live)
+    if B <= 3:
+        refq = ref_cpu.RefModel(fft_spec, quant_bf16=True)
+        assert rel_l2(got, refq.forward(x, tn)) < 1.5e-2
+        assert rel_l2(got, ref_fft.forward(x, tn)) < 2e-2
+        z = np.random.default_rng(1).standard_normal((3,) + x.shape).astype(np.float32)
+        betas = beta_schedule(1000)[:3]
+        a = diffusion_backward(x, betas, gpu_fft, 3, noise=z, precision="bf16", return_trajectory=False)
+        try:
+            gpu_fft.set_option("transpose", 0)
+            b = diffusion_backward(x, betas, gpu_fft, 3, noise=z, precision="bf16", return_trajectory=False)
+        finally:
+            gpu_fft.set_option("transpose", 1)
+        assert rel_l2(a, b) < 1e-3
+
+
 def test_fft_unet_sampler_fp32_bit_exact(gpu_fft, ref_fft):
     """Full 1000-step schedule on the 2-channel spectral state with injected noise (this variant's
     dynamics is stable, std(x) stays O(10)), then irfft2 + sign against numpy."""

@@ -498,7 +498,11 @@ struct ConvStage {
             }
             fetched = false;
             static_for<1, NT + 1>([&](auto N) {
-                if (cnt == decltype(N)::value) piece<decltype(N)::value>(j, sl, cb, epi, hook);
+                // (dispatching on the row parity here, so that piece can reuse the half-resolution tile's repeated fragments,
+                // was measured on the 32-column strips of L = 64 / 128: conv6 -0.5 %, conv8 +2.4 %: not done; the eight-wavefront
+                // fused_B does it for its own conv8, where it gains 1 %)
+                if (cnt != decltype(N)::value) return;
+                piece<decltype(N)::value>(j, sl, cb, epi, hook);
             });
             f += cnt;
         }

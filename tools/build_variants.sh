@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds tuning variants of the fused kernels: each argument is "name:-DIDM_CFG_X=... [-D...]".
+# Builds tuning variants of the fused and strip kernels: each argument is "name:-DIDM_CFG_X=... [-D...]".
 # The libraries land in diffusion-model_amd/isingdiff/abl/lib_<name>.so (git-ignored).
 set -e
 cd "$(dirname "$0")/../diffusion-model_amd/csrc"
@@ -18,7 +18,8 @@ for spec in "$@"; do
   esac
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize $flags -c idm_fused.hip -o /tmp/var_$name.o &&
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize $flags -c idm_fused_split.hip -o /tmp/var_${name}_split.o &&
-    hipcc --offload-arch=gfx950 -shared -fPIC -o ../isingdiff/abl/lib_$name.so $api idm_canon.o idm_fast.o idm_strip.o idm_tileconv.o idm_bitflip.o idm_mlp.o idm_fft.o idm_comm.o idm_xy.o /tmp/var_$name.o /tmp/var_${name}_split.o || echo "FAILED $name" ) &
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize $flags -c idm_strip.hip -o /tmp/var_${name}_strip.o &&
+    hipcc --offload-arch=gfx950 -shared -fPIC -o ../isingdiff/abl/lib_$name.so $api idm_canon.o idm_fast.o /tmp/var_${name}_strip.o idm_tileconv.o idm_bitflip.o idm_mlp.o idm_fft.o idm_comm.o idm_xy.o /tmp/var_$name.o /tmp/var_${name}_split.o || echo "FAILED $name" ) &
 done
 wait
 ls ../isingdiff/abl

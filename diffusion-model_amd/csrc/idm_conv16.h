@@ -192,6 +192,9 @@ struct ConvMfma16 {
 #pragma unroll
                 for (int hc = 0; hc < 2; ++hc) {
                     const f32x4 v = acc[g][n][hc];
+#ifdef IDM_EXP_C7_RAW   // timing experiment (wrong results): conv7 stores its pre-activations (what moving the activation to the copy wavefronts would leave here)
+                    if constexpr (!OUT_HALO) { *(bf16x4 *)(dst0[g] + n * PO + hc * 32) = pack4(v[0], v[1], v[2], v[3]); continue; }
+#endif
                     *(bf16x4 *)(dst0[g] + n * PO + hc * 32) = pack4(silu1(v[0]), silu1(v[1]), silu1(v[2]), silu1(v[3]));
                 }
     }

@@ -11,7 +11,8 @@
 // then refuses to create handles unless ISINGDIFF_ALLOW_EXPERIMENT=1 is set, so such a library cannot pass for the product.
 #if (defined(IDM_EXP_NOSILU) || defined(IDM_EXP_FOLDSILU) || defined(IDM_SILU_SCALAR) || defined(IDM_EXP_HALFW) || \
      defined(IDM_EXP_NOMFMA) || defined(IDM_EXP_MFMA16) || defined(IDM_EXP_NOPHILOX) || defined(IDM_EXP_ONE_WG) ||    \
-     defined(IDM_EXP_PRIO_MFMA) || defined(IDM_EXP_PRIO_EPI)) && !defined(IDM_EXPERIMENT)
+     defined(IDM_EXP_PRIO_MFMA) || defined(IDM_EXP_PRIO_EPI) || defined(IDM_EXP_C7_RAW) || defined(IDM_EXP_RIDE8_RAW)) && \
+    !defined(IDM_EXPERIMENT)
 #error "IDM_EXP_* / IDM_SILU_SCALAR are timing experiments: build the whole library with -DIDM_EXPERIMENT as well"
 #endif
 

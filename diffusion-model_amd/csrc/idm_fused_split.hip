@@ -296,6 +296,137 @@ hipError_t launch_m3_split(const FusedArgs &a, int64_t B, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------
+// fused_M1 (pooled skip1 -> conv2 -> conv3 -> skip2 + 2x2 average pool, whole 16x16 map of the L = 32 pyramid) on
+// v_mfma_f32_16x16x32_bf16: four wavefronts per workgroup, two workgroups per CU (one's epilogues and copies run beside
+// the other's MFMA loops), every wavefront one ConvMfma16 run per convolution (32 couts x 8 rows).  LDS per workgroup:
+// input tile 17 x 18 x 96 B, mid tile 17 x 18 x 160 B, constants - 77 KB; conv3's output is staged OVER the mid tile
+// (plain [16][16] positions of 144 B), so
+//     [registers -> input tile]
+//  B1 input tile complete, and the previous lattice's copy-out has read the staging tile
+//     clear the mid tile's zero row and halo columns (the staged output lay over them)
+//     conv2: loop, epilogue -> mid tile
+//  B2 mid tile complete
+//     conv3: loop;  B2' every wavefront has issued its last MFMA on the mid tile;  request the next lattice's input;
+//     epilogue -> staging tile
+//  B3 staging tile complete
+//     copy-out: skip2 and its pooled copy
+// Same partition and epilogue arithmetic as the 32x32x16 whole-map instance of fused2_kernel; results differ from it by
+// summation order only.
+// ---------------------------------------------------------------------------------------------
+template <int WD1, int WD2>
+__global__ __launch_bounds__(256, 2) void fused_m1_mf16_kernel(FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int W = 16, H = 16, CB = 32, C1 = 64, C2 = 64;
+    constexpr int SB = CB * 2 + 32, SM = C1 * 2 + 32, SO = C2 * 2 + 16;
+    constexpr int ROWS = H + 1;                       // tile rows: the shared zero row, then the map's rows
+    constexpr int TILE_B = ROWS * (W + 2) * SB, MID = ROWS * (W + 2) * SM;
+    static_assert(H * W * SO <= MID, "the staging tile lies over the mid tile");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nlat = (int)a.B;
+    char *tile_b = smem, *mid = smem + TILE_B, *stage = mid;
+    float *cst = (float *)(smem + TILE_B + MID);
+    for (int i = tid; i < C1; i += 256) cst[i] = a.b1[i];
+    for (int i = tid; i < C2; i += 256) cst[C1 + i] = a.b2[i];
+
+    ConvMfma16<0, CB, C1, WD1, SM, true> c2;
+    ConvMfma16<0, C1, C2, WD2, SO, false> c3;
+    const int sl = wave >> 1, j0 = (wave & 1) * 4;
+    c2.setup(nullptr, tile_b, cst, a.w1_alt, mid, lane, sl, j0);
+    c3.setup(nullptr, mid, cst + C1, a.w2_alt, stage, lane, sl, j0);
+
+    TileRegs<CB, 5, 256, 32> rb;
+    auto pf_load = [&](int b) {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        __builtin_assume(t >= 0 && t < 256);
+        rb.load((const __bf16 *)a.in_a + (size_t)b * H * W * CB, H, W, -1, ROWS, t);
+    };
+    const int first = (int)blockIdx.x, step = (int)gridDim.x;
+    if (first < nlat) {
+        pf_load(first);
+        c2.prologue();
+    }
+    for (int b = first; b < nlat; b += step) {
+        {
+            int t = threadIdx.x;
+            asm volatile("" : "+v"(t));
+            __builtin_assume(t >= 0 && t < 256);
+            rb.template store<true>(tile_b, W, ROWS, t);
+            __syncthreads();                   // B1
+            // (after the barrier: before it another wavefront may still be copying the previous lattice's staged output,
+            // which lies over these rows and columns, out; conv2's epilogue writes the interior only, conv3 reads after B2)
+            clear_halo<C1, 256, 32>(mid, W, ROWS, 0, 1, t);
+        }
+        c2.run();
+        c3.prologue();
+        __syncthreads();                       // B2
+        // B2' between conv3's loop and its epilogue; the next lattice's input is requested there, so that its registers
+        // are not live inside the MFMA loops (the last lattice requests its own input again, discarded: an unconditional
+        // request keeps the registers from being loop-carried)
+        c3.run([&] {
+            __syncthreads();
+            pf_load(b + step < nlat ? b + step : b);
+        });
+        if (b + step < nlat) c2.prologue();
+        __syncthreads();                       // B3
+        // (the thread index is made opaque per lattice: otherwise the copy-out's per-thread offsets are hoisted out of the
+        // lattice loop and held - spilled - across the convolutions)
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        __builtin_assume(t >= 0 && t < 256);
+        constexpr int CH = C2 / 8;
+        __bf16 *og = (__bf16 *)a.out + (size_t)b * H * W * C2;
+        for (int i = t; i < H * W * CH; i += 256) {
+            const int ch = i % CH, pos = i / CH;
+            *(bf16x8 *)(og + (size_t)pos * C2 + ch * 8) = *(const bf16x8 *)(stage + pos * SO + ch * 16);
+        }
+        constexpr int Wh = W / 2, Hh = H / 2;
+        __bf16 *pg = (__bf16 *)a.out_pool + (size_t)b * Hh * Wh * C2;
+        for (int i = t; i < Hh * Wh * CH; i += 256) {
+            const int ch = i % CH, pos = i / CH;
+            const int xh = pos % Wh, yh = pos / Wh;
+            const char *q = stage + ((2 * yh) * W + 2 * xh) * SO + ch * 16;
+            const bf16x8 t0 = *(const bf16x8 *)q, t1 = *(const bf16x8 *)(q + SO);
+            const bf16x8 t2 = *(const bf16x8 *)(q + W * SO), t3 = *(const bf16x8 *)(q + W * SO + SO);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                o[j] = (__bf16)((((float)t0[j] + (float)t1[j]) + (float)t2[j] + (float)t3[j]) * 0.25f);
+            *(bf16x8 *)(pg + (size_t)pos * C2 + ch * 8) = o;
+        }
+    }
+}
+
+#ifndef IDM_M1_MFMA16_WD
+#define IDM_M1_MFMA16_WD 2, 2   // supersteps of weights in flight ahead of their MFMAs: conv2 (three supersteps), conv3 (six)
+#endif
+hipError_t launch_m1_mf16(const FusedArgs &a, int64_t B, hipStream_t s)
+{
+    auto kernel = fused_m1_mf16_kernel<IDM_M1_MFMA16_WD>;
+    constexpr int lds = 17 * 18 * 96 + 17 * 18 * 160 + (64 + 64) * 4;
+    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    static thread_local struct { bool configured = false; int cus = 0; } all_st[IDM_MAX_DEVICES];
+    const int slot = idm_device_slot();
+    if (slot < 0) return hipErrorInvalidDevice;
+    auto &st = all_st[slot];
+    if (!st.configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+        st.cus = prop.multiProcessorCount;
+        st.configured = true;
+    }
+    if (a.H != 16 || a.W != 16 || !a.w1_alt || !a.w2_alt) return hipErrorInvalidValue;
+    if (B >= ((int64_t)1 << 30)) return hipErrorInvalidValue;
+    const int64_t grid = std::min<int64_t>(B, (int64_t)st.cus * 2);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // fused_B (conv8, conv9, 1x1 head, reverse update) for the L = 32 lattice: one workgroup per CU, two lattices
 // ("streams" X and Y, each with its own input tiles, mid tile and score tile: 2 x 76 KB) in flight.
 //
@@ -406,7 +537,11 @@ __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
         auto ride8 = [&](const f32x16 &t0, const f32x16 &t1, char *dst, auto C) {
             constexpr int c = decltype(C)::value, n = c >> 3, g = (c >> 1) & 3, hf = c & 1;
             const f32x16 &t = n ? t1 : t0;
+#ifdef IDM_EXP_RIDE8_RAW   // timing experiment (wrong results): conv8 stores its pre-activations
+            const float s0 = t[4 * g + 2 * hf], s1 = t[4 * g + 2 * hf + 1];
+#else
             const float s0 = silu1(t[4 * g + 2 * hf]), s1 = silu1(t[4 * g + 2 * hf + 1]);
+#endif
             if constexpr (hf == 0) { h0 = s0; h1 = s1; }
             else *(bf16x4 *)(dst + n * ROWB + 16 * g) = pack4(h0, h1, s0, s1);
         };
@@ -436,6 +571,9 @@ __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
             static_for<0, 16>([&](auto C) { ride9(t0, t1, dst, C); });
         };
         // conv8 of stream s; `ride` finishes the pending piece; the new accumulators go to (q0, q1), their target to d8
+#ifdef IDM_TIMELINE
+        int tls_n = 0;
+#endif
         auto conv8 = [&](int s, Item it, f32x16 &q0, f32x16 &q1, auto &&ride, auto &&flush) {
             if (it.act) {
                 int rlo, rhi;
@@ -457,9 +595,14 @@ __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
                 auto inter = [&](auto ST) { chunks_of(ST, std::integral_constant<int, Conv1::NS>{}, ride); };
                 // (the parity of the piece's first window row is known per band: the half-resolution tile's fragments are
                 // then read once per half-resolution row)
-                if (cs1.f1 - cs1.f == 3) cs1.template piece<3>(cs1.f, 0, 0, sink, nohook, inter);
-                else if ((rlo + cs1.f) & 1) cs1.template piece<2, 1>(cs1.f, 0, 0, sink, nohook, inter);
-                else cs1.template piece<2, 0>(cs1.f, 0, 0, sink, nohook, inter);
+#ifdef IDM_TIMELINE   // stamps 8-10: operands addressed / last MFMA issued / sinks done (stream X)
+                auto tlhook = [&](int i) { if (s == 0 && i < 3) TLS(8 + i); };
+#else
+                auto &tlhook = nohook;
+#endif
+                if (cs1.f1 - cs1.f == 3) cs1.template piece<3>(cs1.f, 0, 0, sink, tlhook, inter);
+                else if ((rlo + cs1.f) & 1) cs1.template piece<2, 1>(cs1.f, 0, 0, sink, tlhook, inter);
+                else cs1.template piece<2, 0>(cs1.f, 0, 0, sink, tlhook, inter);
                 d8 = nd;
             } else {
                 flush();
@@ -477,7 +620,12 @@ __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
                     else q1 = acc;
                 };
                 auto inter = [&](auto ST) { chunks_of(ST, std::integral_constant<int, Conv2::NS>{}, ride); };
-                cs.template piece<2>(2 * rw, 0, 0, sink, nohook, inter);
+#ifdef IDM_TIMELINE   // stamps 11-13, as above for conv9 (stream X)
+                auto tlhook = [&](int i) { if (s == 0 && i < 3) TLS(11 + i); };
+#else
+                auto &tlhook = nohook;
+#endif
+                cs.template piece<2>(2 * rw, 0, 0, sink, tlhook, inter);
                 d9 = nd;
             } else {
                 flush();
@@ -491,7 +639,7 @@ __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
         for (int q = 0; q < 4; ++q) kw[q] = *(const f32x4 *)(c_wh + 8 * q + 4 * h);
         for (int n = 0; n < niter; ++n) {
 #ifdef IDM_TIMELINE
-            const int tls_n = n;
+            tls_n = n;
 #endif
             const Item X = item_of(0, n), Y = item_of(1, n);
             {   // slot 1: conv8 (X) -> (pa0, pa1); drains the head of Y's previous band (pb0, pb1)

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int dummy)
     const f32x2 c = {0.999f + dummy, 0.001f};
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (MODE >= 10 && (MODE - 10) / 2 == OP_LDS) {
+    if ((MODE >= 10 && (MODE - 10) / 2 == OP_LDS) || MODE == 66 || MODE == 67 || MODE == 76 || MODE == 77) {
         for (int i = threadIdx.x; i < 16384; i += 512) ((float *)smem)[i] = 0.001f * i;
         __syncthreads();
     }
@@ -276,6 +276,49 @@ __global__ __launch_bounds__(512, 2) void k(float *out, int dummy)
 #pragma unroll 1
             for (int it = 0; it < NV / 16 / 8; ++it) exp_block(v);
         }
+    } else if (MODE >= 60 && MODE <= 79) {
+        // Weight-stream pressure: every KM MFMAs take a fresh A operand (16 bytes per lane = 1 KB per wavefront) from a
+        // window of WIN bytes of global memory that all wavefronts of the CU walk in step (the first to ask misses the
+        // vector L1 when WIN exceeds it, the others hit), requested 4 loads ahead (modes 70-79 repeat 60-69 with 8 ahead).  At KM = 2 and one MFMA wavefront
+        // per SIMD a CU at full MFMA rate asks for 4 KB per 64 cycles = 64 bytes per cycle.
+        constexpr int M = MODE >= 70 ? MODE - 10 : MODE, RD = MODE >= 70 ? 8 : 3;
+        constexpr int KM = (M == 62 || M == 64 || M == 67) ? 4 : (M == 68 ? 1 : 2);
+        constexpr unsigned WIN = M == 60 ? 16384u : 65536u;
+        constexpr bool ALL8 = M == 63 || M == 64;
+        constexpr bool LDSW = M == 66 || M == 67;   // the same stream from LDS instead
+        if (ALL8 || wave < 4) {
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(out + 65536), 0, WIN, 0x00020000);
+            // Lean issue stream (a wavefront issues one instruction per ~8 cycles, so everything beside the MFMAs must fit
+            // 3 slots per MFMA): the lane offset is fixed, steps of a group of four ride in the immediate offset, the scalar
+            // base advances once per eight steps, and the MFMAs read the ring slot in place (the refill is issued after them).
+            const unsigned voff = (threadIdx.x & 63) * 16;
+            u32x4 ring[8];
+            unsigned sbase = 0;
+            auto fetch = [&](unsigned sb, int r) {
+                if constexpr (LDSW) return *(const u32x4 *)(smem + voff + ((sb + r * 1024) & (WIN - 1)));
+                else return __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (r & 3) * 1024, sb + (r >> 2) * 4096, 0);
+            };
+            static_assert(RD == 3 || RD == 8, "ring");
+            constexpr int AHEAD = RD == 8 ? 8 : 4;   // loads in flight: a full ring, or half of it
+#pragma unroll
+            for (int r = 0; r < AHEAD; ++r) ring[r] = fetch(sbase, r);
+#pragma unroll 1
+            for (int it = 0; it < NM / KM / 8; ++it) {
+                const unsigned snext = (sbase + 8192) & (WIN - 1);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const bf16x8 w = __builtin_bit_cast(bf16x8, ring[r]);
+#pragma unroll
+                    for (int i = 0; i < KM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, b, acc[i], 0, 0, 0);
+                    constexpr int AH = AHEAD;
+                    if (AH == 8) ring[r] = fetch(snext, r);
+                    else ring[(r + 4) & 7] = r < 4 ? fetch(sbase, r + 4) : fetch(snext, r - 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                sbase = snext;
+            }
+        }
     } else if (MODE == 5) {
 #pragma unroll 1
         for (int rep = 0; rep < 8; ++rep) {
@@ -324,6 +367,7 @@ int main()
     setvbuf(stdout, nullptr, _IOLBF, 0);
     float *d;
     hipMalloc(&d, 1 << 20);
+    hipMemset(d, 0x3c, 1 << 20);
     printf("NM = %d MFMAs (x32 cycles = %d), NV = %d exps (x16 cycles = %d)\n", NM, NM * 32, NV, NV * 16);
     run<0>("8 wavefronts MFMA (2 per SIMD)", d);
     run<1>("8 wavefronts exp", d);
@@ -367,6 +411,22 @@ int main()
     run<54>("one wavefront per SIMD: v_mov from immediate", d);
     run<55>("one wavefront per SIMD: s_nop 0", d);
     run<56>("one wavefront per SIMD: v_mul_f32 e32, 8 chains", d);
+    run<33>("4 MFMA alone (one wavefront per SIMD)", d);
+    run<60>("4 x (A operand from a 16 KB window per 2 MFMAs)  [ideal 59]", d);
+    run<61>("4 x (A operand from a 64 KB window per 2 MFMAs)", d);
+    run<62>("4 x (A operand from a 64 KB window per 4 MFMAs)", d);
+    run<68>("4 x (A operand from a 64 KB window per MFMA)", d);
+    run<63>("8 x (A operand from a 64 KB window per 2 MFMAs)  [ideal 118]", d);
+    run<64>("8 x (A operand from a 64 KB window per 4 MFMAs)", d);
+    run<66>("4 x (A operand from LDS per 2 MFMAs)", d);
+    run<67>("4 x (A operand from LDS per 4 MFMAs)", d);
+    run<70>("RD 8: 4 x (A operand from a 16 KB window per 2 MFMAs)", d);
+    run<71>("RD 8: 4 x (A operand from a 64 KB window per 2 MFMAs)", d);
+    run<72>("RD 8: 4 x (A operand from a 64 KB window per 4 MFMAs)", d);
+    run<78>("RD 8: 4 x (A operand from a 64 KB window per MFMA)", d);
+    run<73>("RD 8: 8 x (A operand from a 64 KB window per 2 MFMAs)", d);
+    run<74>("RD 8: 8 x (A operand from a 64 KB window per 4 MFMAs)", d);
+    run<76>("RD 8: 4 x (A operand from LDS per 2 MFMAs)", d);
     (void)op_names;
     hipFree(d);
     return 0;

@@ -24,6 +24,13 @@
 // Rows: tile row = global row + 1; the map's top and bottom padding rows (global -1 and 16; half resolution -1 and 8)
 // share the all-zero tile row 0, so a full-resolution tile has 17 rows and a half-resolution one 9.
 // Every address is fixed per wavefront for the whole launch.
+//
+// PAIR geometry (8 x 8 maps, conv4 / conv5): the two "row groups" are two LATTICES whose tiles lie LAT bytes apart, and a
+// 16-pixel MFMA covers rows n and n + 4 of the map (pixels 0-7 and 8-15), so that the four MFMAs of a tap row still read
+// consecutive fragments (fragment e = tile rows e and e + 4, e = 0 .. 5) and a weight fragment feeds eight MFMAs.  Tile
+// rows are 9 positions apart: the right halo column of a row IS the left halo column of the next, and the bottom padding
+// row is the shared zero row 0 again (82 positions per tile).  The conflict argument above holds unchanged: the two
+// 8-pixel halves of a ds_read_b128 lane group are 4 rows apart, an even number of 16-byte units.
 #pragma once
 #include "idm_conv_stage.h"
 
@@ -32,18 +39,22 @@ namespace {
 // CA: channels of the upsampled (half-resolution) part, 0 = none; CB: channels of the full-resolution part.
 // The output goes, activated, to a tile with positions SOUT bytes apart: OUT_HALO = a tile of the layout above (the next
 // stage's input: row + 1, column + 1), else a plain [16][16] staging tile.
-template <int CA, int CB, int COUT, int WD, int SOUT, bool OUT_HALO>
+// PAIR: the lattice-pair geometry for 8 x 8 maps (CA must be 0); TADD: a per-cout constant is added after the activation.
+template <int CA, int CB, int COUT, int WD, int SOUT, bool OUT_HALO, bool PAIR = false, bool TADD = false>
 struct ConvMfma16 {
-    static constexpr int W = 16, SA = CA * 2 + 32, SB = CB * 2 + 32;
+    static constexpr int W = PAIR ? 8 : 16, SA = CA * 2 + 32, SB = CB * 2 + 32;
     static constexpr int NGA = CA / 32, NGB = CB / 32, NCG = NGA + NGB, NS = 3 * NCG, MT16 = COUT / 16;
-    static constexpr int PU = (W / 2 + 2) * SA, PB = (W + 2) * SB, PO = (OUT_HALO ? W + 2 : W) * SOUT;
+    static constexpr int PITCH = PAIR ? W + 1 : W + 2;             // positions from one tile row to the next
+    static constexpr int PU = (W / 2 + 2) * SA, PB = PITCH * SB, PO = (OUT_HALO ? PITCH : W) * SOUT;
     static constexpr int WR = WD + 1;
     static constexpr int ROWS_UP = W / 2 + 1, ROWS_FULL = W + 1;   // tile rows (the shared zero row included)
-    static_assert(WD >= 1 && WD < NS && CB % 32 == 0 && CA % 32 == 0 && COUT % 32 == 0, "shape");
+    static constexpr int PAIR_POS = (W + 1) * (W + 1) + 1;         // positions of a PAIR tile
+    static_assert(WD >= 1 && WD < NS && CB % 32 == 0 && CA % 32 == 0 && COUT % 32 == 0 && !(PAIR && CA), "shape");
 
     const char *ta, *tb;
     char *dst0[2];                  // output tile: first row of each row group, this lane's pixel and first cout
     const float *bias;              // this lane's first cout of the slice
+    const float *tadd = nullptr;    // TADD: likewise
     __amdgpu_buffer_rsrc_t wrsrc;
     unsigned woff;
     // byte offsets of a group's input rows: consecutive rows follow the first by constant steps; only a group's LAST row
@@ -78,6 +89,32 @@ struct ConvMfma16 {
         }
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) cu[kx] = ((x + kx + 1) >> 1) * SA + cb * 16;
+    }
+
+    // PAIR: tile / out = lattice 0's, lattice 1's lie lat_in / lat_out bytes further; sl = the wavefront's 32-cout slice
+    DEVI void setup_pair(const char *tile, int lat_in, const float *c_bias, const float *c_tadd, const void *w16, char *out,
+                         int lat_out, int lane, int sl)
+    {
+        static_assert(!PAIR || CA == 0, "no upsampled part");
+        const int p = pix(lane & 15), hi = p >> 3, col = p & 7, cb = lane >> 4;
+        ta = nullptr; tb = tile;
+        bias = c_bias + 32 * sl + 4 * cb;
+        tadd = c_tadd + 32 * sl + 4 * cb;
+        wrsrc = make_rsrc(w16, 9u * (CA + CB) * COUT * 2u);
+        unsigned o = (unsigned)(lane * 16 + 2 * sl * 1024);
+        asm volatile("" : "+v"(o));
+        woff = o;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            // fragment e reads tile rows e (pixels 0-7) and e + 4 (pixels 8-15); row 9 of the upper half is the zero row 0
+            rb0[g] = g * lat_in + (4 * hi * PITCH + col) * SB + cb * 16;
+            rb5[g] = g * lat_in + ((hi ? 0 : 5) * PITCH + col) * SB + cb * 16;
+            ra0[g] = ra3[g] = 0;
+            const int row = 4 * hi;     // output rows n + 4 hi
+            dst0[g] = out + g * lat_out + (OUT_HALO ? ((row + 1) * PITCH + col + 1) : (row * W + col)) * SOUT + (32 * sl + 4 * cb) * 2;
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) cu[kx] = 0;
     }
 
     template <int S>
@@ -184,6 +221,8 @@ struct ConvMfma16 {
             }
         });
         mid();
+        f32x4 kt[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if constexpr (TADD) { kt[0] = *(const f32x4 *)tadd; kt[1] = *(const f32x4 *)(tadd + 16); }
         // activation and store: this lane's four couts of one pixel per accumulator
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -195,7 +234,10 @@ struct ConvMfma16 {
 #ifdef IDM_EXP_C7_RAW   // timing experiment (wrong results): conv7 stores its pre-activations (what moving the activation to the copy wavefronts would leave here)
                     if constexpr (!OUT_HALO) { *(bf16x4 *)(dst0[g] + n * PO + hc * 32) = pack4(v[0], v[1], v[2], v[3]); continue; }
 #endif
-                    *(bf16x4 *)(dst0[g] + n * PO + hc * 32) = pack4(silu1(v[0]), silu1(v[1]), silu1(v[2]), silu1(v[3]));
+                    if constexpr (TADD)
+                        *(bf16x4 *)(dst0[g] + n * PO + hc * 32) = pack4(silu1(v[0]) + kt[hc][0], silu1(v[1]) + kt[hc][1], silu1(v[2]) + kt[hc][2], silu1(v[3]) + kt[hc][3]);
+                    else
+                        *(bf16x4 *)(dst0[g] + n * PO + hc * 32) = pack4(silu1(v[0]), silu1(v[1]), silu1(v[2]), silu1(v[3]));
                 }
     }
 };

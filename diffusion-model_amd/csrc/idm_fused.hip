@@ -743,7 +743,14 @@ hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
         switch (kind) {
         case FK_A: return launch_one(st[5], fused2_kernel<M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, false, IDM_CFG_A, 32, 8>, a, B, s);
         case FK_M1: return launch_one(st[6], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1, 16, 8>, a, B, s);
-        case FK_M2: return launch_one(st[7], fused2_kernel<M1_PLAIN, 64, 0, 128, 128, E2_STORE, true, IDM_CFG_M2, 8, 8>, a, B, s);
+        case FK_M2: {
+            // the lattice-pair kernel on the 16x16x32 MFMA (idm_fused_split.hip: half the weight stream, 18 % faster, whole
+            // job +2.1 %) when the model carries that packing, unless ISINGDIFF_M2_MFMA16=0 asks for the one-lattice
+            // 32x32x16 instance below (read once per process)
+            static const bool mf16 = [] { const char *e = getenv("ISINGDIFF_M2_MFMA16"); return !(e && e[0] == '0'); }();
+            if (mf16 && a.w1_alt && a.w2_alt && B < ((int64_t)1 << 19)) return launch_m2_pair(a, B, s);
+            return launch_one(st[7], fused2_kernel<M1_PLAIN, 64, 0, 128, 128, E2_STORE, true, IDM_CFG_M2, 8, 8>, a, B, s);
+        }
         case FK_M3: {
             // the schedule of idm_fused_split.hip (tile copies on wavefronts of their own; the same results bit for bit, 7 %
             // faster) unless ISINGDIFF_M3_SPLIT=0 asks for the four-wavefront kernel

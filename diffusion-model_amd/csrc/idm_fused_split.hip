@@ -427,6 +427,138 @@ hipError_t launch_m1_mf16(const FusedArgs &a, int64_t B, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------
+// fused_M2 (pooled skip2 -> conv4 (+ time embedding) -> conv5, whole 8x8 maps of the L = 32 pyramid) on
+// v_mfma_f32_16x16x32_bf16, TWO LATTICES per pass: a wavefront owns one 32-cout slice of both maps (ConvMfma16, PAIR
+// geometry), so a weight fragment feeds eight MFMAs where the one-lattice kernel (two 32-pixel tiles per slice) gets two
+// out of it - the weight stream, which bounds that kernel, halves.  Four wavefronts per workgroup, two workgroups per CU.
+// LDS per workgroup: 2 x 82 positions x 160 B input tiles, 2 x 82 x 288 B mid tiles, constants - 73 KB; conv5's output
+// is staged over each lattice's mid tile (plain [8][8] positions of 272 B).  Barriers as in fused_m1_mf16_kernel.
+// An odd last lattice is paired with itself and stored once.
+// ---------------------------------------------------------------------------------------------
+template <int WD1, int WD2>
+__global__ __launch_bounds__(256, 2) void fused_m2_pair_kernel(FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int W = 8, H = 8, C0 = 64, C1 = 128, C2 = 128;
+    constexpr int S0 = C0 * 2 + 32, SM = C1 * 2 + 32, SO = C2 * 2 + 16;
+    using Conv4 = ConvMfma16<0, C0, C1, WD1, SM, true, true, true>;
+    using Conv5 = ConvMfma16<0, C1, C2, WD2, SO, false, true, false>;
+    constexpr int NPOS = Conv4::PAIR_POS, PITCH = Conv4::PITCH;
+    constexpr int IN_LAT = NPOS * S0, MID_LAT = NPOS * SM;
+    static_assert(H * W * SO <= MID_LAT, "a lattice's staging tile lies over its mid tile");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nlat = (int)a.B, npairs = (nlat + 1) >> 1;
+    char *tile_in = smem, *mid = smem + 2 * IN_LAT;
+    float *cst = (float *)(smem + 2 * IN_LAT + 2 * MID_LAT);
+    for (int i = tid; i < C1; i += 256) {
+        cst[i] = a.b1[i];
+        cst[C1 + i] = a.tadd1[i];
+    }
+    for (int i = tid; i < C2; i += 256) cst[2 * C1 + i] = a.b2[i];
+    // input tiles: only the interior is ever written; halo positions and the zero row stay zero
+    {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int i = tid * 16; i < 2 * IN_LAT; i += 256 * 16) *(f32x4 *)(tile_in + i) = z;
+    }
+
+    Conv4 c4;
+    Conv5 c5;
+    c4.setup_pair(tile_in, IN_LAT, cst, cst + C1, a.w1_alt, mid, MID_LAT, lane, wave);
+    c5.setup_pair(mid, MID_LAT, cst + 2 * C1, nullptr, a.w2_alt, mid, MID_LAT, lane, wave);
+
+    // a pair's input: 2 lattices x 64 positions x 8 items of 8 channels, four items per thread
+    bf16x8 rin[4];
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in_a, (unsigned)std::min<int64_t>((int64_t)nlat * H * W * C0 * 2, 0xFFFFFFFFll));
+    auto pf_load = [&](int p) {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        __builtin_assume(t >= 0 && t < 256);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = t + k * 256, g = i >> 9;
+            const int lat = min(2 * p + g, nlat - 1);
+            rin[k] = buf_load16(rs_in, (unsigned)((lat * 512 + (i & 511)) * 16), 0);
+        }
+    };
+    const int first = (int)blockIdx.x, step = (int)gridDim.x;
+    if (first < npairs) {
+        pf_load(first);
+        c4.prologue();
+    }
+    __syncthreads();                           // constants, zeroed input tiles
+    for (int p = first; p < npairs; p += step) {
+        {
+            int t = threadIdx.x;
+            asm volatile("" : "+v"(t));
+            __builtin_assume(t >= 0 && t < 256);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = t + k * 256, g = i >> 9, pos = (i & 511) >> 3, ch = i & 7;
+                *(bf16x8 *)(tile_in + g * IN_LAT + (((pos >> 3) + 1) * PITCH + (pos & 7) + 1) * S0 + ch * 16) = rin[k];
+            }
+            __syncthreads();                   // B1: input tiles complete; the previous pair's copy-out has read the staging tiles
+            // the mid tiles' zero row (positions 0 .. 9) and halo positions (9 r, r = 1 .. 9): the staged output lay over them
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            constexpr int U = SM / 16;         // 16-byte units per position
+            for (int i = t; i < 2 * 19 * U; i += 256) {
+                const int g = i / (19 * U), r = i - g * (19 * U), q = r / U, u = r - q * U;
+                const int pos = q < 10 ? q : (q - 9) * PITCH;
+                *(f32x4 *)(mid + g * MID_LAT + pos * SM + u * 16) = z;
+            }
+        }
+        c4.run();
+        c5.prologue();
+        __syncthreads();                       // B2: mid tiles complete
+        c5.run([&] {
+            __syncthreads();                   // B2': every wavefront has issued its last MFMA on the mid tiles
+            pf_load(p + step < npairs ? p + step : p);
+        });
+        if (p + step < npairs) c4.prologue();
+        __syncthreads();                       // B3: staging tiles complete
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        __builtin_assume(t >= 0 && t < 256);
+        constexpr int CH = C2 / 8;             // 16 items per position
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = t + k * 256, g = i >> 10, r = i & 1023;
+            const int lat = 2 * p + g;
+            if (lat < nlat)
+                *(bf16x8 *)((__bf16 *)a.out + (size_t)lat * H * W * C2 + (size_t)r * 8) =
+                    *(const bf16x8 *)(mid + g * MID_LAT + (r / CH) * SO + (r % CH) * 16);
+        }
+    }
+}
+
+#ifndef IDM_M2_MFMA16_WD
+#define IDM_M2_MFMA16_WD 2, 2   // supersteps of weights in flight ahead of their MFMAs: conv4 (six supersteps), conv5 (twelve)
+#endif
+hipError_t launch_m2_pair(const FusedArgs &a, int64_t B, hipStream_t s)
+{
+    auto kernel = fused_m2_pair_kernel<IDM_M2_MFMA16_WD>;
+    constexpr int lds = 2 * 82 * 160 + 2 * 82 * 288 + 3 * 128 * 4;
+    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    static thread_local struct { bool configured = false; int cus = 0; } all_st[IDM_MAX_DEVICES];
+    const int slot = idm_device_slot();
+    if (slot < 0) return hipErrorInvalidDevice;
+    auto &st = all_st[slot];
+    if (!st.configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+        st.cus = prop.multiProcessorCount;
+        st.configured = true;
+    }
+    if (a.H != 8 || a.W != 8 || !a.w1_alt || !a.w2_alt || !a.tadd1) return hipErrorInvalidValue;
+    if (B >= ((int64_t)1 << 19)) return hipErrorInvalidValue;   // the input (8 KB per lattice) is addressed through one 4 GiB buffer resource
+    const int64_t grid = std::min<int64_t>((B + 1) / 2, (int64_t)st.cus * 2);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // fused_B (conv8, conv9, 1x1 head, reverse update) for the L = 32 lattice: one workgroup per CU, two lattices
 // ("streams" X and Y, each with its own input tiles, mid tile and score tile: 2 x 76 KB) in flight.
 //

@@ -139,6 +139,9 @@ hipError_t launch_b_split(const FusedArgs &a, int64_t B, hipStream_t s);
 hipError_t launch_m3_split(const FusedArgs &a, int64_t B, hipStream_t s);
 // fused_M1 on the whole 16 x 16 map of the L = 32 pyramid on v_mfma_f32_16x16x32_bf16 (idm_fused_split.hip); needs w1_alt / w2_alt
 hipError_t launch_m1_mf16(const FusedArgs &a, int64_t B, hipStream_t s);
+// fused_M2 on the 8 x 8 maps of the L = 32 pyramid, two lattices per pass, on v_mfma_f32_16x16x32_bf16 (idm_fused_split.hip);
+// needs w1_alt / w2_alt; B < 2^19
+hipError_t launch_m2_pair(const FusedArgs &a, int64_t B, hipStream_t s);
 
 // ---- single-convolution band/strip kernels (idm_strip.hip) ----
 enum StripKindId { SK_CONV1 = 0, SK_CONV2, SK_CONV3, SK_CONV4, SK_CONV5, SK_CONV6, SK_CONV7, SK_CONV8, SK_CONV9, SK_CONV9S, SK_CONV9H2, SK_COUNT };   // SK_CONV9: conv9 + head + update; SK_CONV9S: conv9 stored; SK_CONV9H2: conv9 + two-channel head

@@ -461,7 +461,7 @@ def test_copy_wavefront_kernels_are_bit_identical_to_the_four_wavefront_ones(gpu
         "for B in (1, 5, 777, 2049):\n"
         "    r = sample(m, B, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision='bf16', keep_state=True)\n"
         "    np.save(os.path.join(sys.argv[1], f'{sys.argv[2]}{B}.npy'), r.x_final.cpu().numpy())\n")
-    switches = ("ISINGDIFF_M3_SPLIT", "ISINGDIFF_B_SPLIT", "ISINGDIFF_M3_DEFER", "ISINGDIFF_B_DEFER", "ISINGDIFF_M3_MFMA16", "ISINGDIFF_M1_MFMA16")
+    switches = ("ISINGDIFF_M3_SPLIT", "ISINGDIFF_B_SPLIT", "ISINGDIFF_M3_DEFER", "ISINGDIFF_B_DEFER", "ISINGDIFF_M3_MFMA16", "ISINGDIFF_M1_MFMA16", "ISINGDIFF_M2_MFMA16")
     assert not any(k in os.environ for k in switches)
     # (every variant, and the base it is compared with, runs conv6 + conv7 on the 32x32x16 MFMA: the default 16x16x32
     # instance sums in another order and is held to a tolerance by the test below)
@@ -469,7 +469,7 @@ def test_copy_wavefront_kernels_are_bit_identical_to_the_four_wavefront_ones(gpu
                 ("d", {"ISINGDIFF_M3_DEFER": "0", "ISINGDIFF_B_DEFER": "0"}))
     for tag, env in variants:
         subprocess.run([sys.executable, "-c", code, str(tmp_path), tag], check=True,
-                       env=dict(os.environ, ISINGDIFF_M3_MFMA16="0", ISINGDIFF_M1_MFMA16="0", **env), timeout=240)
+                       env=dict(os.environ, ISINGDIFF_M3_MFMA16="0", ISINGDIFF_M1_MFMA16="0", ISINGDIFF_M2_MFMA16="0", **env), timeout=240)
     variants = variants[1:]
     for B in (1, 5, 777, 2049):
         want = np.load(tmp_path / f"base{B}.npy")
@@ -563,6 +563,54 @@ def test_conv2_conv3_on_the_16x16x32_mfma_match_the_32x32x16_kernel(gpu_real, re
         got_s, got_t = np.load(tmp_path / f"s{B}.npy"), np.load(tmp_path / f"t{B}.npy")
         assert np.isfinite(got_s).all() and np.isfinite(got_t).all()
         assert rel_l2(got_t, want_t[3].cpu().numpy()) < 4e-3, B
+        assert rel_l2(got_s, want_s.cpu().numpy()) < 1e-2, B
+        if B <= 5:
+            for s_ in (got_s, want_s.cpu().numpy()):
+                assert rel_l2(s_, refq.forward(xs[B], np.float32(0.6))) < BF16_LAYER_TOL
+                assert rel_l2(s_, ref_real.forward(xs[B], np.float32(0.6))) < BF16_SCORE_TOL
+    want = sample(gpu_real, 777, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision="bf16", keep_state=True)
+    assert rel_l2(np.load(tmp_path / "xs.npy"), want.x_final.cpu().numpy()) < 1e-2
+
+
+# the fused_M2 kernel that is NOT the default (the switch is read once per process)
+M2_ALT_ENV = {"ISINGDIFF_M2_MFMA16": "0"}
+
+
+def test_conv4_conv5_on_lattice_pairs_match_the_one_lattice_kernel(gpu_real, real_spec, ref_real, tmp_path):
+    """conv4 and conv5 of the L=32 bf16 sampler have a kernel that runs two lattices per pass on v_mfma_f32_16x16x32_bf16
+    (8x8 maps, a weight fragment feeds both); M2_ALT_ENV selects the one that is not the default.  Same products, another
+    summation order: conv5's map within 4e-3 relative L2 of each other, the score within 1e-2 and within the bf16
+    tolerances of the oracle, for odd and even batches (an odd last lattice is paired with itself); three sampler steps
+    stay within 1e-2.  (The switch is read once per process.)"""
+    import os, subprocess, sys
+    from oracle import ref_cpu
+    from isingdiff.sampler import sample, beta_schedule
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {os.path.join(root, 'diffusion-model_amd')!r})\n"
+        "from isingdiff import load_model, sample, beta_schedule\n"
+        f"m = load_model({os.path.join(root, 'weights', 'b_diffusion_model_2d_ising_realspace_unet.keras')!r}, device=0, precision='bf16')\n"
+        "for B in (1, 5, 300):\n"
+        "    x = np.load(os.path.join(sys.argv[1], f'x{B}.npy'))\n"
+        "    s, taps = m.forward_taps(x, np.float32(0.6), precision='bf16')\n"
+        "    np.save(os.path.join(sys.argv[1], f's{B}.npy'), s.cpu().numpy())\n"
+        "    np.save(os.path.join(sys.argv[1], f't{B}.npy'), taps[5].cpu().numpy())\n"
+        "r = sample(m, 777, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision='bf16', keep_state=True)\n"
+        "np.save(os.path.join(sys.argv[1], 'xs.npy'), r.x_final.cpu().numpy())\n")
+    rng = np.random.default_rng(63)
+    xs = {}
+    for B in (1, 5, 300):
+        xs[B] = ising_like(rng, B, 32, 32, 600)
+        np.save(tmp_path / f"x{B}.npy", xs[B])
+    assert "ISINGDIFF_M2_MFMA16" not in os.environ
+    subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, env=dict(os.environ, **M2_ALT_ENV), timeout=240)
+    refq = ref_cpu.RefModel(real_spec, quant_bf16=True)
+    for B in (1, 5, 300):
+        want_s, want_t = gpu_real.forward_taps(xs[B], np.float32(0.6), precision="bf16")
+        got_s, got_t = np.load(tmp_path / f"s{B}.npy"), np.load(tmp_path / f"t{B}.npy")
+        assert np.isfinite(got_s).all() and np.isfinite(got_t).all()
+        assert rel_l2(got_t, want_t[5].cpu().numpy()) < 4e-3, B
         assert rel_l2(got_s, want_s.cpu().numpy()) < 1e-2, B
         if B <= 5:
             for s_ in (got_s, want_s.cpu().numpy()):

@@ -816,7 +816,7 @@ int idm_model_create(idm_model **out, int device, const idm_model_desc *d)
             std::vector<float> pf = pack_weights_f32(d->conv_w[i], cin[i], cout[i]);
             rc = upload(m, pb.data(), pb.size(), (uint16_t **)&m->wpack_bf16[i]);
             if (rc == IDM_OK) rc = upload(m, pf.data(), pf.size(), (float **)&m->wpack_f32[i]);
-            if (rc == IDM_OK && i >= 2 && i <= 7 && !m->bn) {   // the layers on the 16 x 16 and 8 x 8 maps at L = 32
+            if (rc == IDM_OK && i >= 2 && i <= 8 && !m->bn) {   // the layers on the 16 x 16 and 8 x 8 maps at L = 32, and conv8 (ninth row of a top band)
                 std::vector<uint16_t> p16 = pack_weights_bf16_m16(d->conv_w[i], cin[i], cout[i]);
                 rc = upload(m, p16.data(), p16.size(), (uint16_t **)&m->wpack_m16[i]);
             }

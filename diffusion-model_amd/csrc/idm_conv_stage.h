@@ -200,6 +200,7 @@ struct ConvStage {
     unsigned wlane, woff;
     LaneGeo g;
     int h, r0, nrows, Rh, f, f1, up_rb;
+    int dual_off = 0;   // piece<.., DUAL = true>: bytes from the tiles this stage reads to the second lattice's tiles
     bf16x8 wreg[WR][3][MS];
     // A stage whose weights fit the ring as a whole (FULL) and that has a single cout slice needs them fetched only
     // once per kernel: they stay in registers from band to band (IDM_STATIONARY_WEIGHTS, on by default).
@@ -308,7 +309,23 @@ struct ConvStage {
     // caller knows it (0 / 1; -1 = unknown).  Two full-resolution rows share one half-resolution row, so of the N + 2
     // fragments of an upsampled channel group only every other one differs: with the parity known those are read once
     // and reused (N = 2: two or three LDS reads per superstep instead of four).
-    template <int N, int UPPAR = -1, class Epi, class Hook, class Inter = NoInter>
+    // DUAL: the piece is computed for TWO lattices at once - the second one's tiles lie dual_off bytes behind the first's
+    // and hold the same rows - with the same weight fragments (each then feeds 2 N MFMAs); epi is handed the second
+    // lattice's tiles as tiles N .. 2 N - 1 (an epi that takes the tile index tells them apart).
+    // Index of the fragment that holds fragment i of an upsampled channel group when the parity UPPAR of the piece's first
+    // window row is known: two full-resolution rows that halve to the same row share one fragment (fragment i repeats
+    // fragment i - 1 when i + UPPAR is odd).
+    template <int UPPAR>
+    static constexpr int up_src(int i)
+    {
+#ifdef IDM_NO_UP_DEDUPE
+        return i;
+#else
+        return (UPPAR >= 0 && i > 0 && ((i + UPPAR) & 1)) ? i - 1 : i;
+#endif
+    }
+
+    template <int N, int UPPAR = -1, bool DUAL = false, class Epi, class Hook, class Inter = NoInter>
     DEVI void piece(int j, int sl, int cb, Epi &&epi, Hook &&hook, Inter &&inter = Inter{})
     {
         const int W = g.W, Wp2 = W + 2, Wh2 = (W >> 1) + 2;
@@ -352,18 +369,24 @@ struct ConvStage {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) k0[m][q] = *(const f32x4 *)(c0 + (sl * MS + m) * 32 + 8 * q + 4 * h);
         }
-        f32x16 acc[MS][N];
+        constexpr int NY = DUAL ? N : 1;
+        f32x16 acc[MS][N], accy[MS][NY];
 #pragma unroll
         for (int m = 0; m < MS; ++m)
 #pragma unroll
             for (int n = 0; n < N; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][r] = BIAS_IN_ACC ? k0[m][r >> 2][r & 3] : 0.0f;
+                for (int r = 0; r < 16; ++r) {
+                    acc[m][n][r] = BIAS_IN_ACC ? k0[m][r >> 2][r & 3] : 0.0f;
+                    if (DUAL) accy[m][n][r] = acc[m][n][r];
+                }
+        (void)accy;
 
         // activation fragments are read FD supersteps ahead of their MFMAs (LDS latency under load exceeds the MFMA time
         // of a superstep with few tiles)
         constexpr int FD = IDM_FRAG_DEPTH < NS ? IDM_FRAG_DEPTH : 1, FR = FD + 1;
-        bf16x8 fr[FR][N + 2];
+        bf16x8 fr[FR][N + 2], fy[DUAL ? FR : 1][N + 2];
+        (void)fy;
         auto read_f = [&](auto S) {
             constexpr int st = decltype(S)::value;
             constexpr int kx = st / NCG, cg = st % NCG;
@@ -372,16 +395,17 @@ struct ConvStage {
                 if constexpr (cg < NCG_A) {
 #ifndef IDM_NO_UP_DEDUPE   // (comparison builds: read every fragment)
                     if constexpr (UP && UPPAR >= 0) {
-                        // fragment i repeats fragment i - 1 when both full-resolution rows halve to the same row
-                        if (i > 0 && ((i + UPPAR) & 1)) { fr[st % FR][i] = fr[st % FR][i - 1]; continue; }
+                        if (up_src<UPPAR>(i) != i) continue;   // fragment i repeats fragment i - 1: the MFMAs read that one
                     }
 #endif
                     int addr;
                     if constexpr (UP) addr = a_up[i] + c_up[kx];
                     else addr = a_pl[i] + kx * SA;
                     fr[st % FR][i] = *(const bf16x8 *)(lds_a + addr + cg * 32);
+                    if constexpr (DUAL) fy[st % FR][i] = *(const bf16x8 *)(lds_a + dual_off + addr + cg * 32);
                 } else {
                     fr[st % FR][i] = *(const bf16x8 *)(lds_b + a_b[i] + kx * SB + (cg - NCG_A) * 32);
+                    if constexpr (DUAL) fy[st % FR][i] = *(const bf16x8 *)(lds_b + dual_off + a_b[i] + kx * SB + (cg - NCG_A) * 32);
                 }
             }
         };
@@ -441,8 +465,16 @@ struct ConvStage {
                         for (int r = 0; r < 4; ++r) { acc[m][n][r] = lo[r]; acc[m][n][4 + r] = hi[r]; acc[m][n][8 + r] = lo[r] * 0.5f; acc[m][n][12 + r] = hi[r] * 0.5f; }
                     }
 #else
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[st % WR][ky][m], fr[st % FR][n + ky],
+                    {
+                        // (an upsampled channel group's fragment may be the copy of its predecessor that was not read)
+                        constexpr bool upg = UP && (st % NCG) < NCG_A;
+                        const int fi = upg ? up_src<UPPAR>(n + ky) : n + ky;
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[st % WR][ky][m], fr[st % FR][fi],
                                                                             acc[m][n], 0, 0, 0);
+                        if constexpr (DUAL)
+                            accy[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[st % WR][ky][m], fy[st % FR][fi],
+                                                                                 accy[m][n], 0, 0, 0);
+                    }
 #endif
         });
 #ifdef IDM_EXP_PRIO_MFMA
@@ -473,6 +505,14 @@ struct ConvStage {
                 epi(acc[m][n], k0[m], k1[m], sl * MS + m, rbase + n, cc, valid);
             if (m * N + n < 3) hook(3 + m * N + n);
         });
+        if constexpr (DUAL) {
+            static_assert(MS == 1 && INDEXED, "the second lattice's tiles are told apart by the tile index");
+            static_for<0, N>([&](auto T) {
+                constexpr int n = decltype(T)::value;
+                const bool valid = g.ok && cc < W && j + n + g.slot * Rh < nrows;
+                epi(std::integral_constant<int, N + n>{}, accy[0][n], k0[0], k1[0], sl, rbase + n, cc, valid);
+            });
+        }
 #ifdef IDM_EXP_PRIO_EPI
         __builtin_amdgcn_s_setprio(0);
 #endif

@@ -576,7 +576,11 @@ hipError_t launch_m2_pair(const FusedArgs &a, int64_t B, hipStream_t s)
 // outside the map are cleared by the copy wavefronts while conv8 of that stream runs (its epilogue does not write them).
 // Partition, epilogue arithmetic, Philox counters and update are those of fused2_kernel: same results bit for bit.
 // ---------------------------------------------------------------------------------------------
-template <int NT1, int WD1, int NT2, int WD2, bool DEFER>
+// TOP9 (with DEFER): the ninth conv8 row of a lattice's top band - which otherwise makes one MFMA wavefront's slot half
+// as long again as the others' - is computed by the four copy wavefronts, one 16-pixel x 16-cout quadrant each, on
+// v_mfma_f32_16x16x32_bf16 (27 MFMAs of 16 cycles per SIMD beside the MFMA wavefronts' two rows each).  That row's sums
+// run in another order than the 32x32x16 tiles' (needs the 16x16x32 weight packing, w1_alt).
+template <int NT1, int WD1, int NT2, int WD2, bool DEFER, bool TOP9 = false>
 __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -711,7 +715,8 @@ __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
                 int rlo, rhi;
                 band_geo(it, rlo, rhi);
                 char *m = mid(s);
-                cs1.begin(tile_a(s), tile_b(s), c_b1, nullptr, geo, rlo, rhi - rlo, (const bf16x8 *)a.w1, rw, lane, 0, 4, true);
+                // (TOP9: the top band's ninth row is a copy wavefront's)
+                cs1.begin(tile_a(s), tile_b(s), c_b1, nullptr, geo, rlo, TOP9 ? min(rhi - rlo, R) : rhi - rlo, (const bf16x8 *)a.w1, rw, lane, 0, 4, true);
                 char *nd = nullptr;
                 auto sink = [&](auto T, const f32x16 &acc, const f32x4 *, const f32x4 *, int, int r, int x, bool) {
                     constexpr int n = decltype(T)::value;
@@ -952,6 +957,42 @@ __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
         }
     };
 
+    // TOP9: conv8 on the ninth row of stream s's top band (global row 8 = mid row 9; input rows 7, 8, 9 = rows 9, 10, 11 of
+    // the full-resolution tile and rows 4, 5, 5 of the half-resolution one), activated and stored at once as the MFMA
+    // wavefront's third tile was.  Copy wavefront rw: pixels 16 (rw & 1) .. + 15, couts 16 (rw >> 1) .. + 15.  Operand lane
+    // maps of v_mfma_f32_16x16x32_bf16: lane l -> pixel / cout l & 15, channels 8 (l >> 4) .. + 7 of a 32-channel group
+    // (three groups per tap: two of the upsampled map, one of skip1); D: pixel l & 15, couts 4 (l >> 4) .. + 3.
+    auto top_row = [&](int s, Item it) {
+        if constexpr (TOP9) {
+            if (!it.act || it.y0 != 0) return;
+            constexpr int PU = (W / 2 + 2) * SA, PB = (W + 2) * SB;
+            const int q = lane & 15, cb = lane >> 4, hc = rw >> 1, x = 16 * (rw & 1) + q;
+            const char *ta = tile_a(s) + cb * 16, *tb = tile_b(s) + (9 * (W + 2) + x) * SB + cb * 16;
+            const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.w1_alt, 9u * (CA + CB) * C1 * 2u);
+            unsigned wl = (unsigned)(lane * 16 + hc * 1024);
+            asm volatile("" : "+v"(wl));
+            f32x4 acc = *(const f32x4 *)(c_b1 + 16 * hc + 4 * cb);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                bf16x8 wq[3][3], fq[3][3];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int cg = 0; cg < 3; ++cg) {
+                        wq[kx][cg] = buf_load16(wr, wl, (unsigned)((((ky * 3 + kx) * 3 + cg) * 2) * 1024));
+                        fq[kx][cg] = cg < 2 ? *(const bf16x8 *)(ta + (ky == 0 ? 4 : 5) * PU + ((x + kx + 1) >> 1) * SA + cg * 64)
+                                            : *(const bf16x8 *)(tb + ky * PB + kx * SB);
+                    }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int cg = 0; cg < 3; ++cg) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[kx][cg], fq[kx][cg], acc, 0, 0, 0);
+            }
+            *(bf16x4 *)(mid(s) + (9 * (W + 2) + x + 1) * SM + (16 * hc + 4 * cb) * 2) = pack4(silu1(acc[0]), silu1(acc[1]), silu1(acc[2]), silu1(acc[3]));
+        }
+    };
+    static_assert(!TOP9 || (DEFER && BIAS_IN_ACC), "the ninth-row hand-over belongs to the deferred schedule");
+
     pf_load(ra[0], rb[0], item_of(0, 0));
     pf_load(ra[1], rb[1], item_of(1, 0));
     stage_in(ra[0], rb[0], 0, item_of(0, 0));
@@ -966,8 +1007,10 @@ __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
             const int tls_n = n;
 #endif
             const Item X = item_of(0, n), Y = item_of(1, n);
+            top_row(0, X);
             update(0, item_of(0, n - 1), n - 1);
             BAR(1);
+            top_row(1, Y);
             update(1, item_of(1, n - 1), n - 1);
             stage_in(ra[0], rb[0], 0, item_of(0, n + 1));
             clear_pad_rows(0, X);              // (not in the slot of X's carry copy, which reads the rows this clears)
@@ -1009,19 +1052,365 @@ __global__ __launch_bounds__(512, 1) void fused_b_copy_kernel(FusedArgs a)
     update(1, item_of(1, niter - 1), niter - 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// fused_B with the two streams MERGED: conv8 and conv9 run on X's and Y's band in ONE MFMA loop each (ConvStage::piece in
+// its two-lattice mode), so a weight fragment feeds four MFMAs instead of two and a pair of bands takes three barriers
+// instead of four slots' set-up:
+//
+//     MFMA wavefronts 0-3                               copy wavefronts 4-7
+//     conv8 (X, Y): loop; the heads of the previous      carry rows X, Y; fetch of the x quads to update
+//     bands ride in it -> score tiles
+//  B1 (every wavefront has issued its last MFMA on the input tiles; score tiles complete; carry done)
+//     activation of conv8 (X, Y) -> mid tiles            state update of X's, Y's previous band; padding rows of the mid tiles
+//  B2 (mid tiles complete)
+//     conv9 (X, Y): loop -> pending head accumulators    stage-in of the next bands; prefetch of the bands after
+//  B3
+//
+// conv8's activation runs exposed (no other loop to ride in), which the shared weights and the halved set-up outweigh.
+// A wavefront's third conv8 row (nine-row top band) is a second, one-row piece after the first.  Tiles, partition of the
+// rows, epilogue arithmetic, Philox counters and update are those of fused_b_copy_kernel: same results bit for bit.
+// ---------------------------------------------------------------------------------------------
+template <int WD1, int WD2, bool TOP9 = false>
+__global__ __launch_bounds__(512, 1) void fused_b_pair_kernel(FusedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int W = 32, H = 32, R = 8, CA = 64, CB = 32, C1 = 32, C2 = 32;
+    constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16, SM = C1 * 2 + 16;
+    constexpr int TILE_A = ((R / 2 + 2) * (W / 2 + 2) * SA + 15) & ~15, TILE_B = (R + 4) * (W + 2) * SB;
+    constexpr int IN = TILE_A + TILE_B, MID = (R + 2) * (W + 2) * SM, SCORE = R * W * 4, STREAM = IN + MID + SCORE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool copier = wave >= 4;          // wave-uniform
+    const int rw = wave & 3, rtid = tid & 255;
+    const int h = lane >> 5, li = lane & 31;
+    const int nlat = (int)a.B;
+
+    float *cst = (float *)(smem + 2 * STREAM);
+    const float *c_b1 = cst, *c_b2 = cst + C1, *c_wh = cst + C1 + C2, *c_bh = cst + C1 + 2 * C2;
+    for (int i = tid; i < C1; i += 512) cst[i] = a.b1[i];
+    for (int i = tid; i < C2; i += 512) {
+        cst[C1 + i] = a.b2[i];
+        cst[C1 + C2 + i] = a.w_head[i];
+    }
+    if (tid == 0) cst[C1 + 2 * C2] = a.b_head[0];
+    auto tile_a = [&](int s) { return smem + s * STREAM; };
+    auto tile_b = [&](int s) { return smem + s * STREAM + TILE_A; };
+    auto mid = [&](int s) { return smem + s * STREAM + IN; };
+    auto score = [&](int s) { return (float *)(smem + s * STREAM + IN + MID); };
+    for (int s = 0; s < 2; ++s) {
+        clear_halo<C1, 512>(mid(s), W, R + 2, 0, 0, tid);                  // halo columns: never written afterwards
+        clear_halo<CA, 512>(tile_a(s), W >> 1, (R >> 1) + 2, 0, 0, tid);
+        clear_halo<CB, 512>(tile_b(s), W, R + 4, 0, 0, tid);
+    }
+
+    // Item n of stream s: band n % 4 of the workgroup's (n / 4)-th lattice of that stream.
+    struct Item { int b, y0; bool act; };
+    auto item_of = [&](int s, int n) {
+        Item it;
+        const int k = n >> 2;
+        it.b = (int)blockIdx.x + (2 * k + s) * (int)gridDim.x;
+        it.y0 = (n & 3) * R;
+        it.act = n >= 0 && it.b < nlat;
+        return it;
+    };
+    auto band_geo = [&](Item it, int &rlo, int &rhi) {
+        rlo = it.y0 == 0 ? 1 : 2;
+        rhi = min(R + 2, H - it.y0 + 1);
+    };
+    const int per = 2 * (int)gridDim.x;
+    const int nx = (int)blockIdx.x < nlat ? (nlat - 1 - (int)blockIdx.x) / per + 1 : 0;
+    const int niter = nx * 4;   // stream Y ends no later than stream X
+    const LaneGeo geo = make_geo(W, li);
+
+    if (!copier) {
+        static_assert(BIAS_IN_ACC && W == 32 && R == 8, "one row per tile, full eight-row bands, the bias in the accumulators");
+        using Conv1 = ConvStage<CA, CB, true, C1, 2, 1, WD1, false, true>;
+        using Conv2 = ConvStage<C1, 0, false, C2, 2, 1, WD2, true, true>;
+        Conv1 cs1;
+        Conv2 cs2;
+        cs1.set_weights((const bf16x8 *)a.w1, lane);
+        cs2.set_weights((const bf16x8 *)a.w2, lane);
+        cs1.dual_off = STREAM;
+        cs2.dual_off = STREAM;
+        cs2.begin(mid(0), nullptr, c_b2, c_wh, geo, 0, R, (const bf16x8 *)a.w2, rw, lane, 0, 4, true);
+        cs2.set_slice(0);
+        constexpr int ROWB = (W + 2) * SM;
+        char *const dummy = smem + 2 * STREAM + 512;            // 3 KB behind the constants: stores of a stream without work
+        f32x4 kw[4];                                            // the head's weights of this lane's channels
+        f32x16 ph[4];                                           // pending conv9 accumulators: rows 2 rw, 2 rw + 1 of X, then of Y
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ph[n][i] = 0.0f;
+        float *d9[2] = {(float *)dummy, (float *)dummy};       // where the pending head values of X / Y go
+        f32x4 p4a = {0.f, 0.f, 0.f, 0.f};
+        // chunk c of 32: values 2 (c & 1), 2 (c & 1) + 1 of quad (c >> 1) & 3 of pending tile c >> 3
+        auto ride9 = [&](auto C) {
+            constexpr int c = decltype(C)::value, n = c >> 3, g = (c >> 1) & 3, hf = c & 1;
+            const f32x16 &t = ph[n];
+            const float s0 = silu1(t[4 * g + 2 * hf]), s1 = silu1(t[4 * g + 2 * hf + 1]);
+            if constexpr (g == 0) p4a[2 * hf] = p4a[2 * hf + 1] = 0.0f;
+            p4a[2 * hf] += s0 * kw[g][2 * hf];           // (the same expression, hence the same contraction, as the
+            p4a[2 * hf + 1] += s1 * kw[g][2 * hf + 1];   // four-at-a-time form of the undeferred epilogue)
+            if constexpr ((c & 7) == 7) {
+                float part = (p4a[0] + p4a[1]) + (p4a[2] + p4a[3]);
+                part += __shfl_xor(part, 32, 64);
+                if (h == 0) d9[n >> 1][(n & 1) * W] = part + c_bh[0];
+            }
+        };
+        auto act_store = [&](const f32x16 &acc, char *dst) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(bf16x4 *)(dst + 16 * g) = pack4(silu1(acc[4 * g]), silu1(acc[4 * g + 1]), silu1(acc[4 * g + 2]), silu1(acc[4 * g + 3]));
+        };
+        cs1.arm();
+        __syncthreads();                       // constants, halo columns, the first bands' tiles
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kw[q] = *(const f32x4 *)(c_wh + 8 * q + 4 * h);
+        for (int n = 0; n < niter; ++n) {
+#ifdef IDM_TIMELINE
+            const int tls_n = n;
+#endif
+            const Item X = item_of(0, n), Y = item_of(1, n);
+            // ---- conv8 (X, Y); the pending heads ride in its loop; B1 between the loop and the activation ----
+            {
+                int rlo, rhi;
+                band_geo(X, rlo, rhi);      // (X is active in every iteration; Y is in the same band of its lattice)
+                // (TOP9: the top band's ninth row is the copy wavefronts')
+                cs1.begin(tile_a(0), tile_b(0), c_b1, nullptr, geo, rlo, TOP9 ? min(rhi - rlo, R) : rhi - rlo, (const bf16x8 *)a.w1, rw, lane, 0, 4, true);
+                char *const mx = mid(0), *const my = mid(1);
+                f32x16 q[4];
+                char *dx = nullptr;
+                auto sink = [&](auto T, const f32x16 &acc, const f32x4 *, const f32x4 *, int, int r, int x, bool) {
+                    constexpr int t = decltype(T)::value;
+                    q[t] = acc;
+                    if constexpr (t == 0) dx = (char *)(size_t)(__mul24(__mul24(r, W + 2) + x + 1, SM) + 8 * h);
+                };
+                auto inter = [&](auto ST) {
+                    constexpr int st = decltype(ST)::value, NS = Conv1::NS;
+                    static_for<32 * st / NS, 32 * (st + 1) / NS>(ride9);
+                };
+                auto hook = [&](int i) { if (i == 1) BAR(1); };
+                if ((rlo + cs1.f) & 1) cs1.template piece<2, 1, true>(cs1.f, 0, 0, sink, hook, inter);
+                else cs1.template piece<2, 0, true>(cs1.f, 0, 0, sink, hook, inter);
+                const size_t off = (size_t)dx;
+                const bool yact = Y.act;
+                act_store(q[0], mx + off);
+                act_store(q[1], mx + off + ROWB);
+                act_store(q[2], yact ? my + off : dummy);
+                act_store(q[3], yact ? my + off + ROWB : dummy);
+                if (cs1.f1 - cs1.f == 3) {
+                    // the nine-row top band gives one wavefront a third row: a one-row piece, finished at once
+                    cs1.prologue();
+                    size_t o3 = 0;
+                    f32x16 q3[2];
+                    auto sink3 = [&](auto T, const f32x16 &acc, const f32x4 *, const f32x4 *, int, int r, int x, bool) {
+                        constexpr int t = decltype(T)::value;
+                        q3[t] = acc;
+                        if constexpr (t == 0) o3 = (size_t)(__mul24(__mul24(r, W + 2) + x + 1, SM) + 8 * h);
+                    };
+                    auto nohook = [](int) {};
+                    if ((rlo + cs1.f) & 1) cs1.template piece<1, 1, true>(cs1.f + 2, 0, 0, sink3, nohook);
+                    else cs1.template piece<1, 0, true>(cs1.f + 2, 0, 0, sink3, nohook);
+                    act_store(q3[0], mx + o3);
+                    act_store(q3[1], yact ? my + o3 : dummy);
+                }
+                cs1.arm();
+                cs2.prologue();             // (here, not a slot earlier: its registers would be live across conv8's loop)
+            }
+            BAR(2);
+            // ---- conv9 (X, Y) -> pending ----
+            {
+                float *sx = score(0), *sy = Y.act ? score(1) : (float *)dummy;
+                auto sink = [&](auto T, const f32x16 &acc, const f32x4 *, const f32x4 *, int, int r, int x, bool) {
+                    constexpr int t = decltype(T)::value;
+                    ph[t] = acc;
+                    if constexpr (t == 0) {
+                        d9[0] = sx + r * W + x;
+                        d9[1] = Y.act ? sy + r * W + x : (float *)dummy;
+                    }
+                };
+                auto nohook = [](int) {};
+                cs2.template piece<2, -1, true>(2 * rw, 0, 0, sink, nohook);
+            }
+            BAR(3);
+        }
+        static_for<0, 32>(ride9);              // the heads of the last bands
+        __syncthreads();
+        return;
+    }
+
+    // ------------------------------ copy wavefronts ------------------------------
+    TileRegs<CA, 3, 256> ra[2];
+    TileRegs<CB, 6, 256> rb[2];
+    auto pf_load = [&](auto &qa, auto &qb, Item it) {
+        if (!it.act) return;
+        int t = rtid;
+        asm volatile("" : "+v"(t));
+        __builtin_assume(t >= 0 && t < 256);
+        qa.load((const __bf16 *)a.in_a + (size_t)it.b * (H / 2) * (W / 2) * CA, H / 2, W / 2, (it.y0 >> 1) - 1, (R >> 1) + 2, t);
+        qb.load((const __bf16 *)a.in_b + (size_t)it.b * H * W * CB, H, W, it.y0 - 2, R + 4, t);
+    };
+    auto stage_in = [&](auto &qa, auto &qb, int s, Item it) {
+        if (!it.act) return;
+        int t = rtid;
+        asm volatile("" : "+v"(t));
+        __builtin_assume(t >= 0 && t < 256);
+        qa.template store<false>(tile_a(s), W >> 1, (R >> 1) + 2, t);
+        qb.template store<false>(tile_b(s), W, R + 4, t);
+    };
+    // rows of the mid tile outside the map are conv9's zero padding
+    auto clear_pad_rows = [&](int s, Item it) {
+        if (!it.act) return;
+        int rlo, rhi;
+        band_geo(it, rlo, rhi);
+        if (it.y0 == 0) clear_halo<C1, 256>(mid(s), W, 0, 0, 1, rtid);
+        if (rhi < R + 2) clear_halo<C1, 256>(mid(s), W, 0, rhi, R + 2, rtid);
+    };
+    // rows R, R+1 of the mid tile are rows 0, 1 of the lattice's next band (it: the band just finished)
+    auto carry = [&](int s, Item it) {
+        if (!it.act || it.y0 + R >= H) return;
+        char *m = mid(s);
+        const int bytes = 2 * (W + 2) * SM;
+        const char *src = m + R * (W + 2) * SM;
+        for (int i = rtid * 16; i < bytes; i += 256 * 16) *(f32x4 *)(m + i) = *(const f32x4 *)(src + i);
+    };
+    // The 64 float4 quads of a band (one Philox counter each) are one wavefront's worth of lanes: the copy wavefronts take
+    // the bands in turn (see fused_b_copy_kernel).
+    f32x4 xq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, zq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    auto my_turn = [&](int s, int n) { return ((n + 2 * s) & 3) == rw; };
+    auto quad_of = [&](Item it, int &qs, int64_t &off) {
+        const int qr = lane >> 3, qx = lane & 7;
+        qs = qr * W + qx * 4;
+        off = (int64_t)it.b * (H * W) + (it.y0 + qr) * W + qx * 4;
+    };
+    auto x_fetch = [&](int s, Item it, int n) {
+        if (!it.act || !a.do_update || !my_turn(s, n)) return;
+        int qs;
+        int64_t off;
+        quad_of(it, qs, off);
+        xq[s] = *(const f32x4 *)(a.x + off);
+        if (a.add_noise && a.noise) zq[s] = *(const f32x4 *)(a.noise + off);
+    };
+    auto update = [&](int s, Item it, int n) {
+        if (!it.act || !my_turn(s, n)) return;
+        int qs;
+        int64_t off;
+        quad_of(it, qs, off);
+        const f32x4 sc = *(const f32x4 *)(score(s) + qs);
+        if (a.score_out) *(f32x4 *)(a.score_out + off) = sc;
+        if (a.do_update) {
+            float z[4] = {zq[s][0], zq[s][1], zq[s][2], zq[s][3]};
+            if (a.add_noise && !a.noise) {
+                uint32_t k0 = (uint32_t)a.ph.seed, k1 = (uint32_t)(a.ph.seed >> 32);
+                normal4(((uint64_t)k1 << 32) | k0, a.ph.first_global_index + it.b, (uint32_t)((off - (int64_t)it.b * (H * W)) >> 2),
+                        a.ph.t, z);
+            }
+            f32x4 xv = xq[s];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[j] = reverse_update(a.c1, xv[j], a.beta, sc[j], z[j], a.sd, a.add_noise != 0);
+            *(f32x4 *)(a.x + off) = xv;
+        }
+    };
+
+    // TOP9, as in fused_b_copy_kernel: conv8 on the ninth row of stream s's top band (global row 8 = mid row 9; input rows 7, 8, 9 = rows 9, 10, 11 of
+    // the full-resolution tile and rows 4, 5, 5 of the half-resolution one), activated and stored at once as the MFMA
+    // wavefront's third tile was.  Copy wavefront rw: pixels 16 (rw & 1) .. + 15, couts 16 (rw >> 1) .. + 15.  Operand lane
+    // maps of v_mfma_f32_16x16x32_bf16: lane l -> pixel / cout l & 15, channels 8 (l >> 4) .. + 7 of a 32-channel group
+    // (three groups per tap: two of the upsampled map, one of skip1); D: pixel l & 15, couts 4 (l >> 4) .. + 3.
+    auto top_row = [&](int s, Item it) {
+        if constexpr (TOP9) {
+            if (!it.act || it.y0 != 0) return;
+            constexpr int PU = (W / 2 + 2) * SA, PB = (W + 2) * SB;
+            const int q = lane & 15, cb = lane >> 4, hc = rw >> 1, x = 16 * (rw & 1) + q;
+            const char *ta = tile_a(s) + cb * 16, *tb = tile_b(s) + (9 * (W + 2) + x) * SB + cb * 16;
+            const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.w1_alt, 9u * (CA + CB) * C1 * 2u);
+            unsigned wl = (unsigned)(lane * 16 + hc * 1024);
+            asm volatile("" : "+v"(wl));
+            f32x4 acc = *(const f32x4 *)(c_b1 + 16 * hc + 4 * cb);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                bf16x8 wq[3][3], fq[3][3];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int cg = 0; cg < 3; ++cg) {
+                        wq[kx][cg] = buf_load16(wr, wl, (unsigned)((((ky * 3 + kx) * 3 + cg) * 2) * 1024));
+                        fq[kx][cg] = cg < 2 ? *(const bf16x8 *)(ta + (ky == 0 ? 4 : 5) * PU + ((x + kx + 1) >> 1) * SA + cg * 64)
+                                            : *(const bf16x8 *)(tb + ky * PB + kx * SB);
+                    }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int cg = 0; cg < 3; ++cg) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[kx][cg], fq[kx][cg], acc, 0, 0, 0);
+            }
+            *(bf16x4 *)(mid(s) + (9 * (W + 2) + x + 1) * SM + (16 * hc + 4 * cb) * 2) = pack4(silu1(acc[0]), silu1(acc[1]), silu1(acc[2]), silu1(acc[3]));
+        }
+    };
+
+    pf_load(ra[0], rb[0], item_of(0, 0));
+    pf_load(ra[1], rb[1], item_of(1, 0));
+    stage_in(ra[0], rb[0], 0, item_of(0, 0));
+    stage_in(ra[1], rb[1], 1, item_of(1, 0));
+    pf_load(ra[0], rb[0], item_of(0, 1));
+    pf_load(ra[1], rb[1], item_of(1, 1));
+    __syncthreads();                           // constants, halo columns, the first bands' tiles
+    for (int n = 0; n < niter; ++n) {
+#ifdef IDM_TIMELINE
+        const int tls_n = n;
+#endif
+        const Item X = item_of(0, n), Y = item_of(1, n);
+        const Item Xp = item_of(0, n - 1), Yp = item_of(1, n - 1);
+        top_row(0, X);
+        top_row(1, Y);
+        carry(0, Xp);
+        carry(1, Yp);
+        x_fetch(0, Xp, n - 1);
+        x_fetch(1, Yp, n - 1);
+        BAR(1);
+        update(0, Xp, n - 1);
+        update(1, Yp, n - 1);
+        clear_pad_rows(0, X);                  // (after the carry copy, which reads the rows this clears)
+        clear_pad_rows(1, Y);
+        BAR(2);
+        stage_in(ra[0], rb[0], 0, item_of(0, n + 1));
+        stage_in(ra[1], rb[1], 1, item_of(1, n + 1));
+        pf_load(ra[0], rb[0], item_of(0, n + 2));
+        pf_load(ra[1], rb[1], item_of(1, n + 2));
+        BAR(3);
+    }
+    __syncthreads();                           // the heads of the last bands
+    x_fetch(0, item_of(0, niter - 1), niter - 1);
+    x_fetch(1, item_of(1, niter - 1), niter - 1);
+    update(0, item_of(0, niter - 1), niter - 1);
+    update(1, item_of(1, niter - 1), niter - 1);
+}
+
 // fused_b_copy_kernel: NT1, WD1, NT2, WD2
 #ifndef IDM_CFG_BSPLIT
 #define IDM_CFG_BSPLIT 3, 2, 2, 3
+#endif
+// fused_b_pair_kernel: WD1, WD2
+#ifndef IDM_CFG_BPAIR
+#define IDM_CFG_BPAIR 1, 2
 #endif
 hipError_t launch_b_split(const FusedArgs &a, int64_t B, hipStream_t s)
 {
     static thread_local struct { bool configured = false; int cus = 0; } all_st[IDM_MAX_DEVICES];
     const int slot = idm_device_slot();
     if (slot < 0) return hipErrorInvalidDevice;
-    auto &st = all_st[slot];
+    auto &st = all_st[slot];   // (one kernel function per process: the switches below are read once)
     // ISINGDIFF_B_DEFER=0: epilogues right after their MFMA loops (comparison runs)
     static const bool defer = [] { const char *e = getenv("ISINGDIFF_B_DEFER"); return !(e && e[0] == '0'); }();
-    auto kernel = defer ? fused_b_copy_kernel<IDM_CFG_BSPLIT, true> : fused_b_copy_kernel<IDM_CFG_BSPLIT, false>;
+    // the merged-stream kernel (same bits as the alternating one; a little faster itself, and it draws less power, which the
+    // other kernels of the step get back as clock: whole job +0.8 %) unless ISINGDIFF_B_PAIR=0
+    static const bool pair = [] { const char *e = getenv("ISINGDIFF_B_PAIR"); return !(e && e[0] == '0'); }();
+    // the top band's ninth conv8 row on the copy wavefronts (merged and deferred schedules; needs w1_alt) unless
+    // ISINGDIFF_B_TOP9=0 (then every row is summed in the order of the four-wavefront kernels)
+    static const bool top9_env = [] { const char *e = getenv("ISINGDIFF_B_TOP9"); return !(e && e[0] == '0'); }();
+    const bool top9 = top9_env && a.w1_alt != nullptr;
+    auto kernel = pair ? (top9 ? fused_b_pair_kernel<IDM_CFG_BPAIR, true> : fused_b_pair_kernel<IDM_CFG_BPAIR>)
+                  : defer ? (top9 ? fused_b_copy_kernel<IDM_CFG_BSPLIT, true, true> : fused_b_copy_kernel<IDM_CFG_BSPLIT, true>)
+                          : fused_b_copy_kernel<IDM_CFG_BSPLIT, false>;
     constexpr int tile_a = ((8 / 2 + 2) * (32 / 2 + 2) * 144 + 15) & ~15, tile_b = 12 * 34 * 80, mid = 10 * 34 * 80, score = 8 * 32 * 4;
     constexpr int lds = 2 * (tile_a + tile_b + mid + score) + 512 + 3072;   // constants (400 B) and the scratch area of the deferred epilogues
     static_assert(lds <= 160 * 1024, "the tiles must fit a CU");

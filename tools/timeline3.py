@@ -21,6 +21,8 @@ sl = slice(4, n - 1)
 per = np.diff(t[0, 4:n, 0]).mean()
 print(f"iterations recorded {n}; period per pair of bands {per:.0f} cycles")
 names = ["conv8 X | update Y', carry", "conv8 Y | stage-in X', prefetch Y'", "conv9 X | stage-in Y', prefetch X''", "conv9 Y | update X, carry"]
+if os.environ.get("ISINGDIFF_B_PAIR") == "1":   # the merged-stream kernel: three barriers per pair of bands
+    names = ["conv8 (X, Y) loop + heads | carry, x fetch", "activation of conv8 (X, Y) | update, padding rows", "conv9 (X, Y) | stage-in, prefetch"]
 NS = len(names)
 for role, rn in ((0, "MFMA wavefront 0"), (1, "other wavefront 4")):
     a = t[role, sl].astype(np.float64)
@@ -32,10 +34,11 @@ for role, rn in ((0, "MFMA wavefront 0"), (1, "other wavefront 4")):
         print(f"   slot {k + 1} ({names[k]}): work {work[:, k].mean():7.0f}   wait at barrier {wait[:, k].mean():7.0f}")
 
 # inside the MFMA wavefront's slots of stream X (stamps 8-13: operands addressed, last MFMA issued, sinks done)
-a = t[0, sl].astype(np.float64)
-dep_prev = t[0, 3:n - 2, 7].astype(np.float64)          # departure from barrier 4 of the previous iteration
-for name, k0, start in (("conv8 X (slot 1)", 8, dep_prev), ("conv9 X (slot 3)", 11, a[:, 3])):
-    ok = a[:, k0] > 0
-    bar = a[:, 0] if k0 == 8 else a[:, 4]
-    print(f"   {name}: set-up {np.mean((a[:, k0] - start)[ok]):6.0f}   MFMA loop {np.mean((a[:, k0 + 1] - a[:, k0])[ok]):6.0f}"
-          f"   sinks {np.mean((a[:, k0 + 2] - a[:, k0 + 1])[ok]):6.0f}   re-arm to barrier {np.mean((bar - a[:, k0 + 2])[ok]):6.0f}")
+if NS == 4:
+    a = t[0, sl].astype(np.float64)
+    dep_prev = t[0, 3:n - 2, 7].astype(np.float64)          # departure from barrier 4 of the previous iteration
+    for name, k0, start in (("conv8 X (slot 1)", 8, dep_prev), ("conv9 X (slot 3)", 11, a[:, 3])):
+        ok = a[:, k0] > 0
+        bar = a[:, 0] if k0 == 8 else a[:, 4]
+        print(f"   {name}: set-up {np.mean((a[:, k0] - start)[ok]):6.0f}   MFMA loop {np.mean((a[:, k0 + 1] - a[:, k0])[ok]):6.0f}"
+              f"   sinks {np.mean((a[:, k0 + 2] - a[:, k0 + 1])[ok]):6.0f}   re-arm to barrier {np.mean((bar - a[:, k0 + 2])[ok]):6.0f}")

@@ -46,7 +46,7 @@ PEAK_HBM_GBS = 8000.0
 # rocprofv3 FETCH_SIZE / WRITE_SIZE passes kept under profiles/ (FETCH_SIZE doubled: gfx950 counts 16-byte-per-lane
 # streaming reads at half their bytes).  Counters cannot be read inside this script; tools/measure_round.sh collects
 # them with the same library.
-PMC_HBM_BYTES_PER_LATTICE = {"fused_B(conv8,9,head,step)": 104.1 * 1024}
+PMC_HBM_BYTES_PER_LATTICE = {"fused_B(conv8,9,head,step)": 104.9 * 1024}
 PMC_SOURCE = "profiles/r03/pmc_hbm.txt"
 
 

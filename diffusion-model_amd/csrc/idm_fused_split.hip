@@ -1,7 +1,12 @@
-// Fused band kernels of the L = 32 pyramid with eight wavefronts per workgroup: four run the MFMA loops and their
-// epilogues, four (the second wavefront of each SIMD) do the tile copies, the noise draw and the state update beside
-// them.  A wavefront issues one instruction per ~8 cycles whatever its kind, so in the four-wavefront kernels that
-// bookkeeping runs while the matrix pipe idles; here it runs in the shadow of the other wavefront's MFMAs.
+// Kernels of the L = 32 pyramid's bf16 schedule that are built around how gfx950 issues instructions - a wavefront issues one
+// instruction per ~8 cycles whatever its kind, so whatever an MFMA wavefront does outside its loops idles the matrix pipe
+// unless another wavefront of the SIMD has MFMAs in flight:
+//   fused_m3_split_kernel   conv6 + conv7, eight wavefronts: four run the MFMA loops and their epilogues, four (the second
+//                           wavefront of each SIMD) the tile copies beside them (the tiles leave room for one workgroup per CU)
+//   fused_b_copy_kernel     conv8 + conv9 + head + update, eight wavefronts likewise, two lattice streams in alternating slots
+//   fused_b_pair_kernel     the same with the two streams merged into one MFMA loop per convolution (the default)
+//   fused_m1_mf16_kernel    conv2 + conv3, four wavefronts, two workgroups per CU, on the 16x16x32 MFMA stage
+//   fused_m2_pair_kernel    conv4 + conv5 likewise, two lattices per pass (a weight fragment feeds both)
 // This translation unit is compiled with -fno-slp-vectorize: the copy wavefronts' arithmetic must stay on the plain
 // (unpacked) float32 ALU, because beside a wavefront that streams MFMAs packed float32 instructions wait for the matrix
 // pipe while plain ones do not (inline assembly is no alternative: the compiler does not see that it consumes a

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -361,6 +362,27 @@ bool idm_fft_supported(int L)
 
 hipError_t launch_irfft2_fft(const float *spec, int64_t B, int L, int8_t *spins, double *real_out, hipStream_t s)
 {
+#ifdef IDM_FFT_TUNE   // tuning builds: ISINGDIFF_FFT_CFG picks a candidate shape (lanes per transform, workgroup size)
+    static const int cfg = [] { const char *e = getenv("ISINGDIFF_FFT_CFG"); return e ? atoi(e) : 0; }();
+    if (L == 32) {
+        switch (cfg) {
+        case 1: return launch_fft<32, 2, 256, 1>(spec, B, spins, real_out, s);
+        case 2: return launch_fft<32, 2, 128, 1>(spec, B, spins, real_out, s);
+        case 3: return launch_fft<32, 4, 256, 1>(spec, B, spins, real_out, s);
+        case 4: return launch_fft<32, 4, 512, 1>(spec, B, spins, real_out, s);
+        case 5: return launch_fft<32, 2, 192, 1>(spec, B, spins, real_out, s);
+        default: break;
+        }
+    }
+    if (L == 20 && cfg == 1) return launch_fft<20, 2, 128, 1>(spec, B, spins, real_out, s);
+    if (L == 64) {
+        switch (cfg) {
+        case 1: return launch_fft<64, 4, 512, 1>(spec, B, spins, real_out, s);
+        case 2: return launch_fft<64, 4, 256, 1>(spec, B, spins, real_out, s);
+        default: break;
+        }
+    }
+#endif
     switch (L) {
     case 4: return launch_fft<4, 1, 128>(spec, B, spins, real_out, s);
     case 8: return launch_fft<8, 1, 128>(spec, B, spins, real_out, s);

@@ -99,7 +99,7 @@ struct ConvMfma16 {
         const int p = pix(lane & 15), hi = p >> 3, col = p & 7, cb = lane >> 4;
         ta = nullptr; tb = tile;
         bias = c_bias + 32 * sl + 4 * cb;
-        tadd = c_tadd + 32 * sl + 4 * cb;
+        tadd = c_tadd ? c_tadd + 32 * sl + 4 * cb : nullptr;
         wrsrc = make_rsrc(w16, 9u * (CA + CB) * COUT * 2u);
         unsigned o = (unsigned)(lane * 16 + 2 * sl * 1024);
         asm volatile("" : "+v"(o));

@@ -665,3 +665,34 @@ def test_ninth_row_of_the_top_band_on_the_copy_wavefronts(gpu_real, tmp_path):
         # 20 000: a few lattices may well agree everywhere, 600 do not)
         if B == 600:
             assert not np.array_equal(got[:, 7:10], want[:, 7:10])
+
+
+def test_merged_fused_b_with_the_ninth_row_hand_over_is_bit_identical_to_the_alternating_kernel(gpu_real, tmp_path):
+    """The default fused_B merges the two lattice streams and gives the top band's ninth conv8 row to the copy wavefronts.
+    ISINGDIFF_B_PAIR=0 runs the alternating-stream kernel with the same ninth-row arithmetic: same bits after three sampler
+    steps, for batches whose second stream runs dry (1, 5), with odd lattice counts per workgroup (777) and with more
+    lattices in one stream than the other (2 049); and the score of a forward call (no update) agrees bit for bit as well.
+    (The switch is read once per process.)"""
+    import os, subprocess, sys
+    from isingdiff.sampler import sample, beta_schedule
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {os.path.join(root, 'diffusion-model_amd')!r})\n"
+        "from isingdiff import load_model, sample, beta_schedule\n"
+        f"m = load_model({os.path.join(root, 'weights', 'b_diffusion_model_2d_ising_realspace_unet.keras')!r}, device=0, precision='bf16')\n"
+        "for B in (1, 5, 777, 2049):\n"
+        "    r = sample(m, B, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision='bf16', keep_state=True)\n"
+        "    np.save(os.path.join(sys.argv[1], f'x{B}.npy'), r.x_final.cpu().numpy())\n"
+        "x = np.load(os.path.join(sys.argv[1], 'in.npy'))\n"
+        "np.save(os.path.join(sys.argv[1], 'score.npy'), np.asarray(m.predict([x, np.float32(0.6)], precision='bf16')))\n")
+    x = ising_like(np.random.default_rng(65), 301, 32, 32, 600)
+    np.save(tmp_path / "in.npy", x)
+    assert "ISINGDIFF_B_PAIR" not in os.environ and "ISINGDIFF_B_TOP9" not in os.environ
+    subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, env=dict(os.environ, ISINGDIFF_B_PAIR="0"), timeout=240)
+    for B in (1, 5, 777, 2049):
+        want = sample(gpu_real, B, 32, T=3, betas=beta_schedule(1000)[:3], seed=5, precision="bf16", keep_state=True)
+        got = np.load(tmp_path / f"x{B}.npy")
+        assert np.isfinite(got).all()
+        assert np.array_equal(got, want.x_final.cpu().numpy()), B
+    assert np.array_equal(np.load(tmp_path / "score.npy"), np.asarray(gpu_real.predict([x, np.float32(0.6)], precision="bf16")))

@@ -104,6 +104,27 @@ std::vector<uint16_t> pack_first_bf16(const float *w, int cout)
     return p;
 }
 
+// Layer 0 of the two-channel model (w: (9, 2, 32) float32, per-cout scale folded in) as bf16 A fragments of two K steps, split
+// into (hi, lo) pairs: [part][step][lane][8], lane l: cout l & 31, k = 16 step + 8 (l >> 5) + j = 2 tap + channel, zero for k >= 18.
+std::vector<uint16_t> pack_first2_bf16(const float *w, const float *scale)
+{
+    std::vector<uint16_t> p(4 * 64 * 8, 0);
+    for (int st = 0; st < 2; ++st)
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * st + 8 * (l >> 5) + j, co = l & 31;
+                if (k >= 18) continue;
+                const float v = w[(size_t)k * 32 + co] * (scale ? scale[co] : 1.0f);
+                const uint16_t hi = bf16_bits(v);
+                uint32_t hb = (uint32_t)hi << 16;
+                float hf;
+                memcpy(&hf, &hb, 4);
+                p[((0 * 2 + st) * 64 + l) * 8 + j] = hi;
+                p[((1 * 2 + st) * 64 + l) * 8 + j] = bf16_bits(v - hf);
+            }
+    return p;
+}
+
 }  // namespace
 
 // Static workspace of idm_forward_noalloc: lives in the code object, one copy per GPU the library runs on,
@@ -169,6 +190,8 @@ struct idm_model {
     void *wpack_fold[IDM_NCONV] = {};      // BatchNorm models: bf16 pack of W*scale (strip kernels)
     void *wpack_tr[IDM_NCONV] = {};        // two-channel models: the strip kernels' pack with the 3x3 taps transposed
     float *w_first_tr = nullptr;           // ... and layer 0's (9, C, F) kernel likewise
+    void *w_first2_pack = nullptr, *w_first2_pack_tr = nullptr;   // C == 2, F == 32: layer 0 as (hi, lo) bf16 MFMA fragments, BatchNorm folded
+    float *bias_first2 = nullptr;          // ... and its folded bias
     bool use_transpose = true;             // two-channel models: process the map transposed when that fills the MFMA lanes
     float *bias_fold[IDM_NCONV] = {};      // bias*scale + shift
     float *bias[IDM_NCONV] = {};
@@ -604,7 +627,11 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
 
     const double npx = (double)Bc * Hp * Wp;
     timed(m, "conv_first", 2.0 * 9 * m->C * F * npx, (double)Bc * p.H * p.W * m->C * 4 + npx * F * p.es, s, [&] {
-        if (bf) launch_conv_first_bf16(x, Bc, p.H, p.W, Hp, Wp, m->C, p.tr ? m->w_first_tr : m->w_first, m->bias[0], m->scale[0], m->shift[0], a0, s, p.tr);
+        // two-channel model: layer 0 on the matrix cores (ISINGDIFF_CONV0_MFMA=0: the vector-ALU kernel; read once per process)
+        static const bool conv0_mfma = [] { const char *e = getenv("ISINGDIFF_CONV0_MFMA"); return !(e && e[0] == '0'); }();
+        const void *w2p = p.tr ? m->w_first2_pack_tr : m->w_first2_pack;
+        if (bf && conv0_mfma && m->C == 2 && w2p && launch_conv_first2_mfma(x, Bc, p.H, p.W, Hp, Wp, w2p, m->bias_first2, a0, s, p.tr)) {}
+        else if (bf) launch_conv_first_bf16(x, Bc, p.H, p.W, Hp, Wp, m->C, p.tr ? m->w_first_tr : m->w_first, m->bias[0], m->scale[0], m->shift[0], a0, s, p.tr);
         else launch_conv_first(x, Bc, p.H, p.W, Hp, Wp, m->C, m->w_first, m->bias[0], m->scale[0], m->shift[0], a0, F, false, s);
     });
 
@@ -804,6 +831,15 @@ int idm_model_create(idm_model **out, int device, const idm_model_desc *d)
                         std::copy(d->conv_w[0] + (size_t)(kx * 3 + ky) * c * f, d->conv_w[0] + (size_t)(kx * 3 + ky + 1) * c * f,
                                   wt.begin() + (size_t)(ky * 3 + kx) * c * f);
                 rc = upload(m, wt.data(), wt.size(), &m->w_first_tr);
+                if (rc == IDM_OK && f == 32) {
+                    const float *sc = m->bn ? d->bn_scale[0] : nullptr, *sh = m->bn ? d->bn_shift[0] : nullptr;
+                    std::vector<uint16_t> pk = pack_first2_bf16(d->conv_w[0], sc), pkt = pack_first2_bf16(wt.data(), sc);
+                    std::vector<float> bf_(32);
+                    for (int k = 0; k < 32; ++k) bf_[k] = d->conv_b[0][k] * (sc ? sc[k] : 1.0f) + (sh ? sh[k] : 0.0f);
+                    rc = upload(m, pk.data(), pk.size(), (uint16_t **)&m->w_first2_pack);
+                    if (rc == IDM_OK) rc = upload(m, pkt.data(), pkt.size(), (uint16_t **)&m->w_first2_pack_tr);
+                    if (rc == IDM_OK) rc = upload(m, bf_.data(), bf_.size(), &m->bias_first2);
+                }
             }
             if (rc == IDM_OK && c == 1) {
                 std::vector<uint16_t> pk = pack_first_bf16(d->conv_w[0], f);

@@ -1,6 +1,8 @@
 // bf16 matrix-core kernels: activations and weights bfloat16, accumulation float32.
 #include "idm_internal.h"
 
+#include <algorithm>
+
 #define DEVI __device__ __forceinline__
 
 DEVI float fast_silu(float y) { return y / (1.0f + __expf(-y)); }
@@ -164,6 +166,93 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
         }
         *(bf16x8 *)(out + p * 32 + 8 * g) = o;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// First layer of the two-channel (spectral) model on the matrix cores: 32 pixels x 32 couts per wavefront and step,
+// K = 9 taps x 2 channels = 18 of the 32 rows of two v_mfma_f32_32x32x16_bf16 steps.  Both operands are split into
+// bf16 (hi, lo) pairs and the three significant products are accumulated (hi*hi + hi*lo + lo*hi: relative error 2^-16, the
+// state and the weights keep their float32 precision), six MFMAs per 32 pixels.  The kernel above spends 576 vector FMAs per
+// pixel on the same sums; this one is bound by its 64 output bytes per pixel.
+// wp: A fragments [part (hi, lo)][k-step][lane][8] (lane l: cout l & 31, k = 16 step + 8 (l >> 5) + j, k = 2 tap + channel),
+// BatchNorm folded into them; biasf: the folded bias.  x: (B, H, W, 2), or (B, W, H, 2) when transposed (see above).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_first2_mfma_kernel(const float *__restrict__ x, int npix, int ntiles, int H, int W, int Hp,
+                                                               int Wp, const bf16x8 *__restrict__ wp, const float *__restrict__ biasf,
+                                                               __bf16 *__restrict__ out, int transposed)
+{
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const bf16x8 ahi0 = wp[lane], ahi1 = wp[64 + lane], alo0 = wp[128 + lane], alo1 = wp[192 + lane];
+    f32x4 kb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) kb[g] = *(const f32x4 *)(biasf + 8 * g + 4 * h);
+    const f32x2 *x2 = (const f32x2 *)x;
+    const int nwaves = (int)gridDim.x * 4;
+    for (int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); tile < ntiles; tile += nwaves) {
+        const int p = tile * 32 + li;
+        const bool valid = p < npix;
+        const unsigned pc = valid ? (unsigned)p : 0u;
+        const unsigned t = pc / (unsigned)Wp, xo = pc - t * (unsigned)Wp, b = t / (unsigned)Hp, yo = t - b * (unsigned)Hp;
+        // this lane's taps: 4 h .. 4 h + 3 (k-step 0) and, for h = 0, tap 8 (k-step 1)
+        f32x2 v[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int tap = i < 4 ? 4 * h + i : 8;
+            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+            const int yy = (int)yo + ky - 1, xx = (int)xo + kx - 1;
+            const bool inb = valid && (i < 4 || h == 0) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const unsigned idx = transposed ? (b * (unsigned)W + (unsigned)xx) * (unsigned)H + (unsigned)yy
+                                            : (b * (unsigned)H + (unsigned)yy) * (unsigned)W + (unsigned)xx;
+            v[i] = inb ? x2[idx] : f32x2{0.f, 0.f};
+        }
+        bf16x8 bhi0, blo0, bhi1, blo1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = v[j >> 1][j & 1];
+            const __bf16 hi = (__bf16)f;
+            bhi0[j] = hi;
+            blo0[j] = (__bf16)(f - (float)hi);
+            const float f1 = j < 2 ? v[4][j] : 0.0f;
+            const __bf16 hi1 = (__bf16)f1;
+            bhi1[j] = hi1;
+            blo1[j] = (__bf16)(f1 - (float)hi1);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = kb[i >> 2][i & 3];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo0, bhi0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi0, blo0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo1, bhi1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi1, blo1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi0, bhi0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi1, bhi1, acc, 0, 0, 0);
+        if (valid) {
+            __bf16 *o = out + (size_t)p * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 r;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float z = acc[4 * g + i];
+                    r[i] = (__bf16)(z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f)));
+                }
+                *(bf16x4 *)(o + 8 * g) = r;
+            }
+        }
+    }
+}
+
+bool launch_conv_first2_mfma(const float *x, int64_t B, int H, int W, int Hp, int Wp, const void *wpack, const float *biasf, void *out,
+                             hipStream_t s, bool transposed)
+{
+    const int64_t npix = B * Hp * Wp;
+    if (npix <= 0 || npix >= ((int64_t)1 << 31) - 64 || B * H * W >= ((int64_t)1 << 31)) return false;   // 32-bit pixel and element indices
+    const int ntiles = (int)((npix + 31) / 32);
+    const unsigned grid = (unsigned)std::min<int64_t>((ntiles + 3) / 4, 256 * 32);
+    hipLaunchKernelGGL(conv_first2_mfma_kernel, dim3(grid), dim3(256), 0, s, x, (int)npix, ntiles, H, W, Hp, Wp, (const bf16x8 *)wpack, biasf,
+                       (__bf16 *)out, transposed ? 1 : 0);
+    return true;
 }
 
 void launch_conv_first_bf16(const float *x, int64_t B, int H, int W, int Hp, int Wp, int C, const float *w, const float *bias,

@@ -63,6 +63,10 @@ void launch_conv_f32(const ConvArgs &a, hipStream_t s);
 // bf16 output, one thread per pixel and 8 channels (idm_fast.hip)
 void launch_conv_first_bf16(const float *x, int64_t B, int H, int W, int Hp, int Wp, int C, const float *w, const float *bias,
                             const float *scale, const float *shift, void *out, hipStream_t s, bool transposed = false);
+// first layer of the two-channel model on the matrix cores, 32 couts (idm_fast.hip); wpack: idm_api.hip's pack_first2_bf16, BatchNorm
+// folded; false: shape beyond 32-bit indexing, nothing launched
+bool launch_conv_first2_mfma(const float *x, int64_t B, int H, int W, int Hp, int Wp, const void *wpack, const float *biasf, void *out,
+                             hipStream_t s, bool transposed);
 void launch_conv_first(const float *x, int64_t B, int H, int W, int Hp, int Wp, int C, const float *w,
                        const float *bias, const float *scale, const float *shift, void *out, int F,
                        bool out_bf16, hipStream_t s);

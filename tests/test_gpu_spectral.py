@@ -94,6 +94,41 @@ def test_fft_unet_bf16_on_the_transposed_map(gpu_fft, ref_fft, fft_spec, B):
         assert rel_l2(a, b) < 1e-3
 
 
+def test_first_layer_on_the_matrix_cores_matches_the_vector_alu_kernel(gpu_fft, tmp_path):
+    """Layer 0 of the two-channel model (K = 9 taps x 2 channels) runs as six MFMAs per 32 pixels, state and folded weights
+    split into bf16 (hi, lo) pairs (hi*hi + hi*lo + lo*hi: 2^-16 relative); ISINGDIFF_CONV0_MFMA=0 selects the kernel that
+    does the same sums with float32 vector FMAs.  Both round the activated map to bf16: layer 0's map agrees but for rare roundings, the scores to 5e-3, for the
+    plain (L = 20) and the transposed (L = 32) schedule, with batches that fill a 32-pixel tile partly.  (The switch is read
+    once per process.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.join(root, 'diffusion-model_amd')!r})\n"
+        "from isingdiff.keras_file import load_unet_spec\n"
+        "from isingdiff.model import ScoreModel\n"
+        f"m = ScoreModel(load_unet_spec({os.path.join(root, 'weights', 'b_diffusion_model_2d_ising_unet.keras')!r}), device=0, precision='fp32')\n"
+        "for tag in ('a', 'b', 'c'):\n"
+        "    x = np.load(os.path.join(sys.argv[1], f'x{tag}.npy'))\n"
+        "    np.save(os.path.join(sys.argv[1], f's{tag}.npy'), np.asarray(m([x, np.float32(0.7)], precision='bf16')))\n"
+        "    np.save(os.path.join(sys.argv[1], f't{tag}.npy'), m.forward_taps(x, np.float32(0.7), precision='bf16')[1][0].cpu().numpy())\n")
+    xs = {"a": spectra(np.random.default_rng(70), 3, 32, 700), "b": spectra(np.random.default_rng(71), 5, 20, 700),
+          "c": spectra(np.random.default_rng(72), 130, 32, 700)}
+    for tag, x in xs.items():
+        np.save(tmp_path / f"x{tag}.npy", x)
+    assert "ISINGDIFF_CONV0_MFMA" not in os.environ
+    subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, env=dict(os.environ, ISINGDIFF_CONV0_MFMA="0"), timeout=240)
+    for tag, x in xs.items():
+        got = np.asarray(gpu_fft([x, np.float32(0.7)], precision="bf16"))
+        want = np.load(tmp_path / f"s{tag}.npy")
+        assert np.isfinite(got).all() and got.shape == want.shape
+        assert rel_l2(got, want) < 5e-3, tag          # (ten more bf16 layers amplify a flipped rounding, as between any two schedules)
+        t0 = gpu_fft.forward_taps(x, np.float32(0.7), precision="bf16")[1][0].cpu().numpy()
+        w0 = np.load(tmp_path / f"t{tag}.npy")
+        assert np.isfinite(t0).all() and rel_l2(t0, w0) < 2e-4, tag          # layer 0 itself: the same bf16 values but for rare roundings
+        assert np.mean(t0 != w0) < 1e-2, tag   # (about one value in 300: sums with cancellation see the 2^-17 of the split)
+
+
 def test_fft_unet_sampler_fp32_bit_exact(gpu_fft, ref_fft):
     """Full 1000-step schedule on the 2-channel spectral state with injected noise (this variant's
     dynamics is stable, std(x) stays O(10)), then irfft2 + sign against numpy."""

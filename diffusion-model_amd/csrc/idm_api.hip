@@ -189,6 +189,7 @@ struct idm_model {
     void *wpack_m16[IDM_NCONV] = {};       // layers whose fused kernel has a 16x16x32-MFMA instance
     void *wpack_fold[IDM_NCONV] = {};      // BatchNorm models: bf16 pack of W*scale (strip kernels)
     void *wpack_tr[IDM_NCONV] = {};        // two-channel models: the strip kernels' pack with the 3x3 taps transposed
+    void *wpack_tr_m16[IDM_NCONV] = {};    // ... and its 16x16x32-MFMA packing for the layers on 5 x 8 maps (conv4, conv5)
     float *w_first_tr = nullptr;           // ... and layer 0's (9, C, F) kernel likewise
     void *w_first2_pack = nullptr, *w_first2_pack_tr = nullptr;   // C == 2, F == 32: layer 0 as (hi, lo) bf16 MFMA fragments, BatchNorm folded
     float *bias_first2 = nullptr;          // ... and its folded bias
@@ -684,6 +685,7 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
             a.w2 = p.tr ? m->wpack_tr[l1 + 1] : m->bn ? m->wpack_fold[l1 + 1] : m->wpack_bf16[l1 + 1];
             a.b2 = m->bn ? m->bias_fold[l1 + 1] : m->bias[l1 + 1];
             a.tadd1 = l1 == 4 ? tadd : nullptr;
+            if (p.tr) { a.w1_alt = m->wpack_tr_m16[l1]; a.w2_alt = m->wpack_tr_m16[l1 + 1]; }
             a.in_a = in_a; a.in_b = in_b; a.out = out; a.out_pool = out_pool;
             a.H = H; a.W = W; a.R = p.R[kind]; a.nbands = (H + a.R - 1) / a.R;
             a.Hx = p.H; a.Wx = p.W; a.B = Bc;
@@ -876,6 +878,10 @@ int idm_model_create(idm_model **out, int device, const idm_model_desc *d)
                                   wt.begin() + (ky * 3 + kx) * per_tap);
                 std::vector<uint16_t> ptr_ = pack_weights_bf16(wt.data(), cin[i], cout[i]);
                 rc = upload(m, ptr_.data(), ptr_.size(), (uint16_t **)&m->wpack_tr[i]);
+                if (rc == IDM_OK && (i == 4 || i == 5)) {
+                    std::vector<uint16_t> p16 = pack_weights_bf16_m16(wt.data(), cin[i], cout[i]);
+                    rc = upload(m, p16.data(), p16.size(), (uint16_t **)&m->wpack_tr_m16[i]);
+                }
             }
         }
     }

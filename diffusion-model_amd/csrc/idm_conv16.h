@@ -40,8 +40,10 @@ namespace {
 // The output goes, activated, to a tile with positions SOUT bytes apart: OUT_HALO = a tile of the layout above (the next
 // stage's input: row + 1, column + 1), else a plain [16][16] staging tile.
 // PAIR: the lattice-pair geometry for 8 x 8 maps (CA must be 0); TADD: a per-cout constant is added after the activation.
-template <int CA, int CB, int COUT, int WD, int SOUT, bool OUT_HALO, bool PAIR = false, bool TADD = false>
+// HROWS (PAIR): rows of the map, 5 .. 8; outputs of rows beyond it are not stored (an OUT_HALO tile keeps them zero).
+template <int CA, int CB, int COUT, int WD, int SOUT, bool OUT_HALO, bool PAIR = false, bool TADD = false, int HROWS = 8>
 struct ConvMfma16 {
+    static_assert(HROWS >= 5 && HROWS <= 8 && (PAIR || HROWS == 8), "map rows");
     static constexpr int W = PAIR ? 8 : 16, SA = CA * 2 + 32, SB = CB * 2 + 32;
     static constexpr int NGA = CA / 32, NGB = CB / 32, NCG = NGA + NGB, NS = 3 * NCG, MT16 = COUT / 16;
     static constexpr int PITCH = PAIR ? W + 1 : W + 2;             // positions from one tile row to the next
@@ -55,6 +57,7 @@ struct ConvMfma16 {
     char *dst0[2];                  // output tile: first row of each row group, this lane's pixel and first cout
     const float *bias;              // this lane's first cout of the slice
     const float *tadd = nullptr;    // TADD: likewise
+    int upper = 0;                  // PAIR: this lane's pixel is in rows 4 .. 7 (n + 4) of the map
     __amdgpu_buffer_rsrc_t wrsrc;
     unsigned woff;
     // byte offsets of a group's input rows: consecutive rows follow the first by constant steps; only a group's LAST row
@@ -98,6 +101,7 @@ struct ConvMfma16 {
         static_assert(!PAIR || CA == 0, "no upsampled part");
         const int p = pix(lane & 15), hi = p >> 3, col = p & 7, cb = lane >> 4;
         ta = nullptr; tb = tile;
+        upper = hi;
         bias = c_bias + 32 * sl + 4 * cb;
         tadd = c_tadd ? c_tadd + 32 * sl + 4 * cb : nullptr;
         wrsrc = make_rsrc(w16, 9u * (CA + CB) * COUT * 2u);
@@ -230,6 +234,9 @@ struct ConvMfma16 {
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int hc = 0; hc < 2; ++hc) {
+                    if constexpr (PAIR && HROWS < 8) {
+                        if (upper && n >= HROWS - 4) continue;   // a row below the map
+                    }
                     const f32x4 v = acc[g][n][hc];
 #ifdef IDM_EXP_C7_RAW   // timing experiment (wrong results): conv7 stores its pre-activations (what moving the activation to the copy wavefronts would leave here)
                     if constexpr (!OUT_HALO) { *(bf16x4 *)(dst0[g] + n * PO + hc * 32) = pack4(v[0], v[1], v[2], v[3]); continue; }

@@ -177,6 +177,9 @@ __global__ __launch_bounds__(256) void conv_first_bf16_kernel(const float *__res
 // wp: A fragments [part (hi, lo)][k-step][lane][8] (lane l: cout l & 31, k = 16 step + 8 (l >> 5) + j, k = 2 tap + channel),
 // BatchNorm folded into them; biasf: the folded bias.  x: (B, H, W, 2), or (B, W, H, 2) when transposed (see above).
 // ---------------------------------------------------------------------------------------------
+// ROWTILE: Wp == W == 32 and the map transposed (the spectral model at L = 32): a tile is one row of one spectrum, so the
+// row and the spectrum are wavefront-uniform (scalar arithmetic) and a lane's column is its index.
+template <bool ROWTILE>
 __global__ __launch_bounds__(256) void conv_first2_mfma_kernel(const float *__restrict__ x, int npix, int ntiles, int H, int W, int Hp,
                                                                int Wp, const bf16x8 *__restrict__ wp, const float *__restrict__ biasf,
                                                                __bf16 *__restrict__ out, int transposed)
@@ -192,19 +195,33 @@ __global__ __launch_bounds__(256) void conv_first2_mfma_kernel(const float *__re
     for (int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); tile < ntiles; tile += nwaves) {
         const int p = tile * 32 + li;
         const bool valid = p < npix;
-        const unsigned pc = valid ? (unsigned)p : 0u;
-        const unsigned t = pc / (unsigned)Wp, xo = pc - t * (unsigned)Wp, b = t / (unsigned)Hp, yo = t - b * (unsigned)Hp;
         // this lane's taps: 4 h .. 4 h + 3 (k-step 0) and, for h = 0, tap 8 (k-step 1)
         f32x2 v[5];
+        if constexpr (ROWTILE) {
+            const unsigned ut = (unsigned)__builtin_amdgcn_readfirstlane(tile);
+            const unsigned b = ut / (unsigned)Hp, yo = ut - b * (unsigned)Hp;
+            const f32x2 *xb = x2 + (size_t)b * 32u * (unsigned)H;       // spectrum b: element (column xx, row yy) at xx * H + yy
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int tap = i < 4 ? 4 * h + i : 8;
-            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-            const int yy = (int)yo + ky - 1, xx = (int)xo + kx - 1;
-            const bool inb = valid && (i < 4 || h == 0) && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const unsigned idx = transposed ? (b * (unsigned)W + (unsigned)xx) * (unsigned)H + (unsigned)yy
-                                            : (b * (unsigned)H + (unsigned)yy) * (unsigned)W + (unsigned)xx;
-            v[i] = inb ? x2[idx] : f32x2{0.f, 0.f};
+            for (int i = 0; i < 5; ++i) {
+                const int tap = i < 4 ? 4 * h + i : 8;
+                const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+                const int yy = (int)yo + ky - 1, xx = li + kx - 1;
+                const bool inb = (i < 4 || h == 0) && yy >= 0 && yy < H && xx >= 0 && xx < 32;
+                v[i] = inb ? xb[xx * H + yy] : f32x2{0.f, 0.f};
+            }
+        } else {
+            const unsigned pc = valid ? (unsigned)p : 0u;
+            const unsigned t = pc / (unsigned)Wp, xo = pc - t * (unsigned)Wp, b = t / (unsigned)Hp, yo = t - b * (unsigned)Hp;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int tap = i < 4 ? 4 * h + i : 8;
+                const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+                const int yy = (int)yo + ky - 1, xx = (int)xo + kx - 1;
+                const bool inb = valid && (i < 4 || h == 0) && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                const unsigned idx = transposed ? (b * (unsigned)W + (unsigned)xx) * (unsigned)H + (unsigned)yy
+                                                : (b * (unsigned)H + (unsigned)yy) * (unsigned)W + (unsigned)xx;
+                v[i] = inb ? x2[idx] : f32x2{0.f, 0.f};
+            }
         }
         bf16x8 bhi0, blo0, bhi1, blo1;
 #pragma unroll
@@ -250,8 +267,12 @@ bool launch_conv_first2_mfma(const float *x, int64_t B, int H, int W, int Hp, in
     if (npix <= 0 || npix >= ((int64_t)1 << 31) - 64 || B * H * W >= ((int64_t)1 << 31)) return false;   // 32-bit pixel and element indices
     const int ntiles = (int)((npix + 31) / 32);
     const unsigned grid = (unsigned)std::min<int64_t>((ntiles + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(conv_first2_mfma_kernel, dim3(grid), dim3(256), 0, s, x, (int)npix, ntiles, H, W, Hp, Wp, (const bf16x8 *)wpack, biasf,
-                       (__bf16 *)out, transposed ? 1 : 0);
+    if (transposed && W == 32 && Wp == 32)
+        hipLaunchKernelGGL(conv_first2_mfma_kernel<true>, dim3(grid), dim3(256), 0, s, x, (int)npix, ntiles, H, W, Hp, Wp, (const bf16x8 *)wpack,
+                           biasf, (__bf16 *)out, 1);
+    else
+        hipLaunchKernelGGL(conv_first2_mfma_kernel<false>, dim3(grid), dim3(256), 0, s, x, (int)npix, ntiles, H, W, Hp, Wp, (const bf16x8 *)wpack,
+                           biasf, (__bf16 *)out, transposed ? 1 : 0);
     return true;
 }
 

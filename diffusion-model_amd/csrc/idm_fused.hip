@@ -768,6 +768,11 @@ hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
         }
         }
     }
+    if (kind == FK_M2 && a.W == 8 && a.H == 5 && a.w1_alt && a.w2_alt && B < ((int64_t)1 << 19)) {
+        // the third level of the transposed spectral model (5 x 8 maps): the lattice-pair kernel as well
+        static const bool mf16 = [] { const char *e = getenv("ISINGDIFF_M2_MFMA16"); return !(e && e[0] == '0'); }();
+        if (mf16) return launch_m2_pair(a, B, s);
+    }
     switch (kind) {
     case FK_A: return launch_one(st[0], fused2_kernel<M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, false, IDM_CFG_A, 0, 0>, a, B, s);
     case FK_M1: return launch_one(st[1], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1, 0, 0>, a, B, s);

@@ -440,17 +440,18 @@ hipError_t launch_m1_mf16(const FusedArgs &a, int64_t B, hipStream_t s)
 // is staged over each lattice's mid tile (plain [8][8] positions of 272 B).  Barriers as in fused_m1_mf16_kernel.
 // An odd last lattice is paired with itself and stored once.
 // ---------------------------------------------------------------------------------------------
-template <int WD1, int WD2>
+// HROWS: rows of the maps (8; 5 for the third level of the transposed spectral model, whose maps are 5 x 8)
+template <int WD1, int WD2, int HROWS = 8>
 __global__ __launch_bounds__(256, 2) void fused_m2_pair_kernel(FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int W = 8, H = 8, C0 = 64, C1 = 128, C2 = 128;
+    constexpr int W = 8, H = HROWS, C0 = 64, C1 = 128, C2 = 128;
     constexpr int S0 = C0 * 2 + 32, SM = C1 * 2 + 32, SO = C2 * 2 + 16;
-    using Conv4 = ConvMfma16<0, C0, C1, WD1, SM, true, true, true>;
-    using Conv5 = ConvMfma16<0, C1, C2, WD2, SO, false, true, false>;
+    using Conv4 = ConvMfma16<0, C0, C1, WD1, SM, true, true, true, HROWS>;
+    using Conv5 = ConvMfma16<0, C1, C2, WD2, SO, false, true, false, HROWS>;
     constexpr int NPOS = Conv4::PAIR_POS, PITCH = Conv4::PITCH;
     constexpr int IN_LAT = NPOS * S0, MID_LAT = NPOS * SM;
-    static_assert(H * W * SO <= MID_LAT, "a lattice's staging tile lies over its mid tile");
+    static_assert(8 * W * SO <= MID_LAT, "a lattice's staging tile ([8][8] positions) lies over its mid tile");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nlat = (int)a.B, npairs = (nlat + 1) >> 1;
     char *tile_in = smem, *mid = smem + 2 * IN_LAT;
@@ -471,18 +472,19 @@ __global__ __launch_bounds__(256, 2) void fused_m2_pair_kernel(FusedArgs a)
     c4.setup_pair(tile_in, IN_LAT, cst, cst + C1, a.w1_alt, mid, MID_LAT, lane, wave);
     c5.setup_pair(mid, MID_LAT, cst + 2 * C1, nullptr, a.w2_alt, mid, MID_LAT, lane, wave);
 
-    // a pair's input: 2 lattices x 64 positions x 8 items of 8 channels, four items per thread
-    bf16x8 rin[4];
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in_a, (unsigned)std::min<int64_t>((int64_t)nlat * H * W * C0 * 2, 0xFFFFFFFFll));
+    // a pair's input: 2 lattices x H * 8 positions x 8 items of 8 channels
+    constexpr int IT = H * W * (C0 / 8), NPI = (2 * IT + 255) / 256;   // items per lattice, per thread
+    bf16x8 rin[NPI];
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in_a, (unsigned)std::min<int64_t>((int64_t)nlat * IT * 16, 0xFFFFFFFFll));
     auto pf_load = [&](int p) {
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));
         __builtin_assume(t >= 0 && t < 256);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = t + k * 256, g = i >> 9;
+        for (int k = 0; k < NPI; ++k) {
+            const int i = t + k * 256, g = i / IT, r = i - g * IT;
             const int lat = min(2 * p + g, nlat - 1);
-            rin[k] = buf_load16(rs_in, (unsigned)((lat * 512 + (i & 511)) * 16), 0);
+            rin[k] = buf_load16(rs_in, i < 2 * IT ? (unsigned)((lat * IT + r) * 16) : 0x80000000u, 0);
         }
     };
     const int first = (int)blockIdx.x, step = (int)gridDim.x;
@@ -497,17 +499,20 @@ __global__ __launch_bounds__(256, 2) void fused_m2_pair_kernel(FusedArgs a)
             asm volatile("" : "+v"(t));
             __builtin_assume(t >= 0 && t < 256);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = t + k * 256, g = i >> 9, pos = (i & 511) >> 3, ch = i & 7;
-                *(bf16x8 *)(tile_in + g * IN_LAT + (((pos >> 3) + 1) * PITCH + (pos & 7) + 1) * S0 + ch * 16) = rin[k];
+            for (int k = 0; k < NPI; ++k) {
+                const int i = t + k * 256, g = i / IT, r = i - g * IT, pos = r >> 3, ch = r & 7;
+                if (i < 2 * IT)
+                    *(bf16x8 *)(tile_in + g * IN_LAT + (((pos >> 3) + 1) * PITCH + (pos & 7) + 1) * S0 + ch * 16) = rin[k];
             }
             __syncthreads();                   // B1: input tiles complete; the previous pair's copy-out has read the staging tiles
-            // the mid tiles' zero row (positions 0 .. 9) and halo positions (9 r, r = 1 .. 9): the staged output lay over them
+            // the mid tiles' zero row (positions 0 .. 9), the halo positions 9 r of rows 2 .. H, and everything from row H + 1
+            // on (its halo position, and the rows below a map of fewer than eight rows): the staged output lay over them
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             constexpr int U = SM / 16;         // 16-byte units per position
-            for (int i = t; i < 2 * 19 * U; i += 256) {
-                const int g = i / (19 * U), r = i - g * (19 * U), q = r / U, u = r - q * U;
-                const int pos = q < 10 ? q : (q - 9) * PITCH;
+            constexpr int NCL = 10 + (H - 1) + (NPOS - (H + 1) * PITCH);
+            for (int i = t; i < 2 * NCL * U; i += 256) {
+                const int g = i / (NCL * U), r = i - g * (NCL * U), q = r / U, u = r - q * U;
+                const int pos = q < 10 ? q : q < 10 + (H - 1) ? (q - 8) * PITCH : (H + 1) * PITCH + (q - 10 - (H - 1));
                 *(f32x4 *)(mid + g * MID_LAT + pos * SM + u * 16) = z;
             }
         }
@@ -524,11 +529,12 @@ __global__ __launch_bounds__(256, 2) void fused_m2_pair_kernel(FusedArgs a)
         asm volatile("" : "+v"(t));
         __builtin_assume(t >= 0 && t < 256);
         constexpr int CH = C2 / 8;             // 16 items per position
+        constexpr int OT = H * W * CH, NPO = (2 * OT + 255) / 256;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = t + k * 256, g = i >> 10, r = i & 1023;
+        for (int k = 0; k < NPO; ++k) {
+            const int i = t + k * 256, g = i / OT, r = i - g * OT;
             const int lat = 2 * p + g;
-            if (lat < nlat)
+            if (i < 2 * OT && lat < nlat)
                 *(bf16x8 *)((__bf16 *)a.out + (size_t)lat * H * W * C2 + (size_t)r * 8) =
                     *(const bf16x8 *)(mid + g * MID_LAT + (r / CH) * SO + (r % CH) * 16);
         }
@@ -540,13 +546,14 @@ __global__ __launch_bounds__(256, 2) void fused_m2_pair_kernel(FusedArgs a)
 #endif
 hipError_t launch_m2_pair(const FusedArgs &a, int64_t B, hipStream_t s)
 {
-    auto kernel = fused_m2_pair_kernel<IDM_M2_MFMA16_WD>;
+    auto kernel = a.H == 5 ? fused_m2_pair_kernel<IDM_M2_MFMA16_WD, 5> : fused_m2_pair_kernel<IDM_M2_MFMA16_WD, 8>;
     constexpr int lds = 2 * 82 * 160 + 2 * 82 * 288 + 3 * 128 * 4;
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-    static thread_local struct { bool configured = false; int cus = 0; } all_st[IDM_MAX_DEVICES];
+    static thread_local struct { bool configured = false; int cus = 0; } all_st[IDM_MAX_DEVICES][2];   // one slot per kernel function
     const int slot = idm_device_slot();
     if (slot < 0) return hipErrorInvalidDevice;
-    auto &st = all_st[slot];
+    if ((a.H != 8 && a.H != 5) || a.W != 8 || !a.w1_alt || !a.w2_alt || !a.tadd1) return hipErrorInvalidValue;
+    auto &st = all_st[slot][a.H == 5];
     if (!st.configured) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -556,7 +563,6 @@ hipError_t launch_m2_pair(const FusedArgs &a, int64_t B, hipStream_t s)
         st.cus = prop.multiProcessorCount;
         st.configured = true;
     }
-    if (a.H != 8 || a.W != 8 || !a.w1_alt || !a.w2_alt || !a.tadd1) return hipErrorInvalidValue;
     if (B >= ((int64_t)1 << 19)) return hipErrorInvalidValue;   // the input (8 KB per lattice) is addressed through one 4 GiB buffer resource
     const int64_t grid = std::min<int64_t>((B + 1) / 2, (int64_t)st.cus * 2);
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, s, a);

@@ -553,7 +553,20 @@ int forward_fused(idm_model *m, const Plan &p, const float *x, const float *tadd
         rc = run(FK_M1, "fused_M1(conv2,3)", a, Hp / 2, Wp / 2, 2.0 * 9 * (F * 2 * F + 4 * F * F) * n2, n2 * F * 2 + n2 * 2 * F * 2 + n4 * 2 * F * 2);
         if (rc != IDM_OK) return rc;
     }
-    if (p.strip[FK_M2]) {
+    // conv4 + conv5 on 16 x 16 maps (L = 64): the whole-map 16x16x32 kernel of idm_fused_split.hip instead of two strip launches
+    // (ISINGDIFF_M2_MFMA16=0: the strips; read once per process)
+    static const bool m2_mf16 = [] { const char *e = getenv("ISINGDIFF_M2_MFMA16"); return !(e && e[0] == '0'); }();
+    if (p.strip[FK_M2] && m2_mf16 && Hp / 4 == 16 && Wp / 4 == 16 && F == 32 && m->wpack_m16[4] && m->wpack_m16[5]) {
+        FusedArgs a = {};
+        layer(a, 4, 5);
+        a.tadd1 = tadd;
+        a.in_a = p2; a.out = a5;
+        a.H = 16; a.W = 16; a.Hx = p.H; a.Wx = p.W; a.B = Bc;
+        hipError_t e = hipSuccess;
+        timed(m, "fused_M2(conv4,5)", 2.0 * 9 * (8 * F * F + 16 * F * F) * n4, n4 * 2 * F * 2 + n4 * 4 * F * 2, s,
+              [&] { e = launch_m1_mf16(a, Bc, s, true); });
+        if (e != hipSuccess) return fail(IDM_ERR_HIP, std::string("launch fused_M2(conv4,5): ") + hipGetErrorString(e));
+    } else if (p.strip[FK_M2]) {
         rc = strip(SK_CONV4, 4, "strip_conv4", p2, nullptr, c4, nullptr, Hp / 4, Wp / 4, 2.0 * 9 * 8 * F * F * n4, n4 * 2 * F * 2 + n4 * 4 * F * 2, false);
         if (rc == IDM_OK)
             rc = strip(SK_CONV5, 5, "strip_conv5", c4, nullptr, a5, nullptr, Hp / 4, Wp / 4, 2.0 * 9 * 16 * F * F * n4, n4 * 4 * F * 4, false);

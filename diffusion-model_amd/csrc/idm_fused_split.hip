@@ -318,11 +318,14 @@ hipError_t launch_m3_split(const FusedArgs &a, int64_t B, hipStream_t s)
 // Same partition and epilogue arithmetic as the 32x32x16 whole-map instance of fused2_kernel; results differ from it by
 // summation order only.
 // ---------------------------------------------------------------------------------------------
-template <int WD1, int WD2>
-__global__ __launch_bounds__(256, 2) void fused_m1_mf16_kernel(FusedArgs a)
+// The same kernel serves conv4 (+ time add) + conv5 where THEIR maps are 16 x 16 (L = 64): CB = 64, C1 = C2 = 128, no pooled
+// copy, eight wavefronts (four cout slices x two row sets) and one workgroup per CU (137 KB of tiles).
+template <int CB, int C1, int C2, bool TADD, bool POOL, int WD1, int WD2>
+__global__ __launch_bounds__(C1 * 4, C1 == 64 ? 2 : 1) void fused_m1_mf16_kernel(FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int W = 16, H = 16, CB = 32, C1 = 64, C2 = 64;
+    constexpr int W = 16, H = 16, NT = C1 * 4;      // threads: two wavefronts (row sets) per 32-cout slice
+    static_assert(C1 == C2 && (C1 == 64 || C1 == 128), "one ConvMfma16 unit per wavefront and convolution");
     constexpr int SB = CB * 2 + 32, SM = C1 * 2 + 32, SO = C2 * 2 + 16;
     constexpr int ROWS = H + 1;                       // tile rows: the shared zero row, then the map's rows
     constexpr int TILE_B = ROWS * (W + 2) * SB, MID = ROWS * (W + 2) * SM;
@@ -331,20 +334,24 @@ __global__ __launch_bounds__(256, 2) void fused_m1_mf16_kernel(FusedArgs a)
     const int nlat = (int)a.B;
     char *tile_b = smem, *mid = smem + TILE_B, *stage = mid;
     float *cst = (float *)(smem + TILE_B + MID);
-    for (int i = tid; i < C1; i += 256) cst[i] = a.b1[i];
-    for (int i = tid; i < C2; i += 256) cst[C1 + i] = a.b2[i];
+    for (int i = tid; i < C1; i += NT) {
+        cst[i] = a.b1[i];
+        if constexpr (TADD) cst[C1 + C2 + i] = a.tadd1[i];   // (a third array of constants only in this instance's LDS size)
+    }
+    for (int i = tid; i < C2; i += NT) cst[C1 + i] = a.b2[i];
 
-    ConvMfma16<0, CB, C1, WD1, SM, true> c2;
+    ConvMfma16<0, CB, C1, WD1, SM, true, false, TADD> c2;
     ConvMfma16<0, C1, C2, WD2, SO, false> c3;
     const int sl = wave >> 1, j0 = (wave & 1) * 4;
     c2.setup(nullptr, tile_b, cst, a.w1_alt, mid, lane, sl, j0);
+    c2.tadd = cst + C1 + C2 + 32 * sl + 4 * (lane >> 4);
     c3.setup(nullptr, mid, cst + C1, a.w2_alt, stage, lane, sl, j0);
 
-    TileRegs<CB, 5, 256, 32> rb;
+    TileRegs<CB, (ROWS * W * (CB / 8) + NT - 1) / NT, NT, 32> rb;
     auto pf_load = [&](int b) {
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));
-        __builtin_assume(t >= 0 && t < 256);
+        __builtin_assume(t >= 0 && t < NT);
         rb.load((const __bf16 *)a.in_a + (size_t)b * H * W * CB, H, W, -1, ROWS, t);
     };
     const int first = (int)blockIdx.x, step = (int)gridDim.x;
@@ -356,12 +363,12 @@ __global__ __launch_bounds__(256, 2) void fused_m1_mf16_kernel(FusedArgs a)
         {
             int t = threadIdx.x;
             asm volatile("" : "+v"(t));
-            __builtin_assume(t >= 0 && t < 256);
+            __builtin_assume(t >= 0 && t < NT);
             rb.template store<true>(tile_b, W, ROWS, t);
             __syncthreads();                   // B1
             // (after the barrier: before it another wavefront may still be copying the previous lattice's staged output,
             // which lies over these rows and columns, out; conv2's epilogue writes the interior only, conv3 reads after B2)
-            clear_halo<C1, 256, 32>(mid, W, ROWS, 0, 1, t);
+            clear_halo<C1, NT, 32>(mid, W, ROWS, 0, 1, t);
         }
         c2.run();
         c3.prologue();
@@ -379,26 +386,28 @@ __global__ __launch_bounds__(256, 2) void fused_m1_mf16_kernel(FusedArgs a)
         // lattice loop and held - spilled - across the convolutions)
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));
-        __builtin_assume(t >= 0 && t < 256);
+        __builtin_assume(t >= 0 && t < NT);
         constexpr int CH = C2 / 8;
         __bf16 *og = (__bf16 *)a.out + (size_t)b * H * W * C2;
-        for (int i = t; i < H * W * CH; i += 256) {
+        for (int i = t; i < H * W * CH; i += NT) {
             const int ch = i % CH, pos = i / CH;
             *(bf16x8 *)(og + (size_t)pos * C2 + ch * 8) = *(const bf16x8 *)(stage + pos * SO + ch * 16);
         }
-        constexpr int Wh = W / 2, Hh = H / 2;
-        __bf16 *pg = (__bf16 *)a.out_pool + (size_t)b * Hh * Wh * C2;
-        for (int i = t; i < Hh * Wh * CH; i += 256) {
-            const int ch = i % CH, pos = i / CH;
-            const int xh = pos % Wh, yh = pos / Wh;
-            const char *q = stage + ((2 * yh) * W + 2 * xh) * SO + ch * 16;
-            const bf16x8 t0 = *(const bf16x8 *)q, t1 = *(const bf16x8 *)(q + SO);
-            const bf16x8 t2 = *(const bf16x8 *)(q + W * SO), t3 = *(const bf16x8 *)(q + W * SO + SO);
-            bf16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                o[j] = (__bf16)((((float)t0[j] + (float)t1[j]) + (float)t2[j] + (float)t3[j]) * 0.25f);
-            *(bf16x8 *)(pg + (size_t)pos * C2 + ch * 8) = o;
+        if constexpr (POOL) {
+            constexpr int Wh = W / 2, Hh = H / 2;
+            __bf16 *pg = (__bf16 *)a.out_pool + (size_t)b * Hh * Wh * C2;
+            for (int i = t; i < Hh * Wh * CH; i += NT) {
+                const int ch = i % CH, pos = i / CH;
+                const int xh = pos % Wh, yh = pos / Wh;
+                const char *q = stage + ((2 * yh) * W + 2 * xh) * SO + ch * 16;
+                const bf16x8 t0 = *(const bf16x8 *)q, t1 = *(const bf16x8 *)(q + SO);
+                const bf16x8 t2 = *(const bf16x8 *)(q + W * SO), t3 = *(const bf16x8 *)(q + W * SO + SO);
+                bf16x8 o;
+    #pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    o[j] = (__bf16)((((float)t0[j] + (float)t1[j]) + (float)t2[j] + (float)t3[j]) * 0.25f);
+                *(bf16x8 *)(pg + (size_t)pos * C2 + ch * 8) = o;
+            }
         }
     }
 }
@@ -406,15 +415,17 @@ __global__ __launch_bounds__(256, 2) void fused_m1_mf16_kernel(FusedArgs a)
 #ifndef IDM_M1_MFMA16_WD
 #define IDM_M1_MFMA16_WD 2, 2   // supersteps of weights in flight ahead of their MFMAs: conv2 (three supersteps), conv3 (six)
 #endif
-hipError_t launch_m1_mf16(const FusedArgs &a, int64_t B, hipStream_t s)
+// wide: the conv4 + conv5 instance (16 x 16 maps of 64 -> 128 -> 128 channels, L = 64)
+hipError_t launch_m1_mf16(const FusedArgs &a, int64_t B, hipStream_t s, bool wide)
 {
-    auto kernel = fused_m1_mf16_kernel<IDM_M1_MFMA16_WD>;
-    constexpr int lds = 17 * 18 * 96 + 17 * 18 * 160 + (64 + 64) * 4;
-    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-    static thread_local struct { bool configured = false; int cus = 0; } all_st[IDM_MAX_DEVICES];
+    auto kernel = wide ? fused_m1_mf16_kernel<64, 128, 128, true, false, IDM_M1_MFMA16_WD> : fused_m1_mf16_kernel<32, 64, 64, false, true, IDM_M1_MFMA16_WD>;
+    constexpr int lds_m1 = 17 * 18 * 96 + 17 * 18 * 160 + (64 + 64) * 4;
+    constexpr int lds_wide = 17 * 18 * 160 + 17 * 18 * 288 + 3 * 128 * 4;
+    static_assert(2 * lds_m1 <= 160 * 1024 && lds_wide <= 160 * 1024, "two workgroups / one workgroup per CU");
+    static thread_local struct { bool configured = false; int cus = 0; } all_st[IDM_MAX_DEVICES][2];   // one slot per kernel function
     const int slot = idm_device_slot();
     if (slot < 0) return hipErrorInvalidDevice;
-    auto &st = all_st[slot];
+    auto &st = all_st[slot][wide ? 1 : 0];
     if (!st.configured) {
         hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -424,10 +435,10 @@ hipError_t launch_m1_mf16(const FusedArgs &a, int64_t B, hipStream_t s)
         st.cus = prop.multiProcessorCount;
         st.configured = true;
     }
-    if (a.H != 16 || a.W != 16 || !a.w1_alt || !a.w2_alt) return hipErrorInvalidValue;
+    if (a.H != 16 || a.W != 16 || !a.w1_alt || !a.w2_alt || (wide && !a.tadd1)) return hipErrorInvalidValue;
     if (B >= ((int64_t)1 << 30)) return hipErrorInvalidValue;
-    const int64_t grid = std::min<int64_t>(B, (int64_t)st.cus * 2);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
+    const int64_t grid = std::min<int64_t>(B, (int64_t)st.cus * (wide ? 1 : 2));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(wide ? 512 : 256), wide ? lds_wide : lds_m1, s, a);
     return hipGetLastError();
 }
 

@@ -142,7 +142,8 @@ hipError_t launch_b_split(const FusedArgs &a, int64_t B, hipStream_t s);
 // fused_M3 for the L = 32 pyramid, tile copies on wavefronts of their own (idm_fused_split.hip)
 hipError_t launch_m3_split(const FusedArgs &a, int64_t B, hipStream_t s);
 // fused_M1 on the whole 16 x 16 map of the L = 32 pyramid on v_mfma_f32_16x16x32_bf16 (idm_fused_split.hip); needs w1_alt / w2_alt
-hipError_t launch_m1_mf16(const FusedArgs &a, int64_t B, hipStream_t s);
+// wide: its conv4 (+ time add) + conv5 instance for 16 x 16 maps of 64 -> 128 -> 128 channels (the third level at L = 64), no pooled copy
+hipError_t launch_m1_mf16(const FusedArgs &a, int64_t B, hipStream_t s, bool wide = false);
 // fused_M2 on the 8 x 8 maps of the L = 32 pyramid, two lattices per pass, on v_mfma_f32_16x16x32_bf16 (idm_fused_split.hip);
 // needs w1_alt / w2_alt; B < 2^19
 hipError_t launch_m2_pair(const FusedArgs &a, int64_t B, hipStream_t s);

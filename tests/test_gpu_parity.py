@@ -696,3 +696,39 @@ def test_merged_fused_b_with_the_ninth_row_hand_over_is_bit_identical_to_the_alt
         assert np.isfinite(got).all()
         assert np.array_equal(got, want.x_final.cpu().numpy()), B
     assert np.array_equal(np.load(tmp_path / "score.npy"), np.asarray(gpu_real.predict([x, np.float32(0.6)], precision="bf16")))
+
+
+def test_conv4_conv5_whole_map_kernel_at_L64_matches_the_strips(gpu_real, real_spec, ref_real, tmp_path):
+    """At L = 64 the third level's maps are 16 x 16: conv4 (+ time embedding) and conv5 run as one whole-map kernel on
+    v_mfma_f32_16x16x32_bf16 (eight wavefronts, 64 -> 128 -> 128 channels) instead of two strip launches
+    (ISINGDIFF_M2_MFMA16=0).  Same products, another summation order: conv5's map within 4e-3 relative L2, the score within
+    1e-2 and within the bf16 tolerance of the float32 oracle, for one, several and many lattices per workgroup.  (The switch
+    is read once per process.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {os.path.join(root, 'diffusion-model_amd')!r})\n"
+        "from isingdiff import load_model\n"
+        f"m = load_model({os.path.join(root, 'weights', 'b_diffusion_model_2d_ising_realspace_unet.keras')!r}, device=0, precision='bf16')\n"
+        "for B in (1, 3, 300):\n"
+        "    x = np.load(os.path.join(sys.argv[1], f'x{B}.npy'))\n"
+        "    s, taps = m.forward_taps(x, np.float32(0.6), precision='bf16')\n"
+        "    np.save(os.path.join(sys.argv[1], f's{B}.npy'), s.cpu().numpy())\n"
+        "    np.save(os.path.join(sys.argv[1], f't{B}.npy'), taps[5].cpu().numpy())\n")
+    rng = np.random.default_rng(66)
+    xs = {}
+    for B in (1, 3, 300):
+        xs[B] = ising_like(rng, B, 64, 64, 600)
+        np.save(tmp_path / f"x{B}.npy", xs[B])
+    assert "ISINGDIFF_M2_MFMA16" not in os.environ
+    subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, env=dict(os.environ, ISINGDIFF_M2_MFMA16="0"), timeout=240)
+    for B in (1, 3, 300):
+        want_s, want_t = gpu_real.forward_taps(xs[B], np.float32(0.6), precision="bf16")
+        got_s, got_t = np.load(tmp_path / f"s{B}.npy"), np.load(tmp_path / f"t{B}.npy")
+        assert np.isfinite(got_s).all() and np.isfinite(got_t).all()
+        assert not np.array_equal(got_t, want_t[5].cpu().numpy())          # (the two paths do differ: the switch is live)
+        assert rel_l2(got_t, want_t[5].cpu().numpy()) < 4e-3, B
+        assert rel_l2(got_s, want_s.cpu().numpy()) < 1e-2, B
+        if B == 1:
+            assert rel_l2(want_s.cpu().numpy(), ref_real.forward(xs[B], np.float32(0.6))) < BF16_SCORE_TOL

@@ -1417,10 +1417,9 @@ __global__ __launch_bounds__(512, 1) void fused_b_pair_kernel(FusedArgs a)
 #endif
 hipError_t launch_b_split(const FusedArgs &a, int64_t B, hipStream_t s)
 {
-    static thread_local struct { bool configured = false; int cus = 0; } all_st[IDM_MAX_DEVICES];
+    static thread_local struct { bool configured = false; int cus = 0; } all_st[IDM_MAX_DEVICES][8];   // one slot per kernel function
     const int slot = idm_device_slot();
     if (slot < 0) return hipErrorInvalidDevice;
-    auto &st = all_st[slot];   // (one kernel function per process: the switches below are read once)
     // ISINGDIFF_B_DEFER=0: epilogues right after their MFMA loops (comparison runs)
     static const bool defer = [] { const char *e = getenv("ISINGDIFF_B_DEFER"); return !(e && e[0] == '0'); }();
     // the merged-stream kernel (same bits as the alternating one; a little faster itself, and it draws less power, which the
@@ -1433,6 +1432,7 @@ hipError_t launch_b_split(const FusedArgs &a, int64_t B, hipStream_t s)
     auto kernel = pair ? (top9 ? fused_b_pair_kernel<IDM_CFG_BPAIR, true> : fused_b_pair_kernel<IDM_CFG_BPAIR>)
                   : defer ? (top9 ? fused_b_copy_kernel<IDM_CFG_BSPLIT, true, true> : fused_b_copy_kernel<IDM_CFG_BSPLIT, true>)
                           : fused_b_copy_kernel<IDM_CFG_BSPLIT, false>;
+    auto &st = all_st[slot][(pair ? 4 : 0) + (defer ? 2 : 0) + (top9 ? 1 : 0)];
     constexpr int tile_a = ((8 / 2 + 2) * (32 / 2 + 2) * 144 + 15) & ~15, tile_b = 12 * 34 * 80, mid = 10 * 34 * 80, score = 8 * 32 * 4;
     constexpr int lds = 2 * (tile_a + tile_b + mid + score) + 512 + 3072;   // constants (400 B) and the scratch area of the deferred epilogues
     static_assert(lds <= 160 * 1024, "the tiles must fit a CU");

@@ -13,7 +13,10 @@
 #include "idm_canon_math.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -35,6 +38,17 @@ DEVI float rsqrt_canon(float v)
     }
     return r;
 }
+
+// Activations between the kernels are float32 (parity mode; bf16 mode on shapes its fused kernels do not cover) or bf16
+// (bf16 mode otherwise: every tensor is rounded once where it is produced, all arithmetic stays float32).
+DEVI f32x4 ld4(const float *p) { return *(const f32x4 *)p; }
+DEVI f32x4 ld4(const __bf16 *p)
+{
+    const bf16x4 v = *(const bf16x4 *)p;
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+DEVI void st4(float *p, f32x4 v) { *(f32x4 *)p = v; }
+DEVI void st4(__bf16 *p, f32x4 v) { *(bf16x4 *)p = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; }
 
 struct TimeW {
     const float *d1_w, *d1_b, *d2_w, *d2_b;
@@ -70,13 +84,14 @@ __global__ __launch_bounds__(128) void bf_time_kernel(const float *__restrict__ 
 }
 
 // Conv2D(32, kernel 1) on the 0/1 image (:207).
+template <typename AT>
 __global__ __launch_bounds__(256) void bf_in_kernel(const uint8_t *__restrict__ x, const float *__restrict__ w,
-                                                    const float *__restrict__ b, float *__restrict__ out, int64_t npix)
+                                                    const float *__restrict__ b, AT *__restrict__ out, int64_t npix)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= npix * 32) return;
     const int c = (int)(i & 31);
-    out[i] = __fadd_rn(__fmaf_rn((float)x[i >> 5], w[c], 0.0f), b[c]);
+    out[i] = (AT)__fadd_rn(__fmaf_rn((float)x[i >> 5], w[c], 0.0f), b[c]);
 }
 
 // GroupNormalization(groups=8) statistics: one wavefront per (sample, group); writes the affine
@@ -164,44 +179,74 @@ __global__ __launch_bounds__(256) void bf_gn_apply_kernel(const float *__restric
 // The input of a ResBlock that follows an upsampling stage, x = Concatenate([UpSampling2D(up), skip]) (:225-226, :230-231),
 // read in place: up is (B, Hh, Wh, Cu), skip is (B, 2 Hh, 2 Wh, Cs).  up == nullptr: a plain tensor.
 struct UpCatSrc {
-    const float *up, *skip;
+    const void *up, *skip;   // float32 or bf16, as the kernel's activation type says
     int Hh, Wh, Cu, Cs;
 };
 
-template <int THREADS, int NV>
-__global__ __launch_bounds__(THREADS) void bf_gn_fused_bf16_kernel(const float *__restrict__ x, UpCatSrc uc, int HW, int C,
-                                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                                   __bf16 *__restrict__ y)
+// workgroups per CU the register budget is set for: packed bf16 input takes 2 NV registers, float32 input 4 NV
+constexpr int gn_blocks_per_cu(int threads, int nv, bool packed)
+{
+    const int need = (packed ? 2 : 4) * nv + 48;
+    int wps = 512 / need;
+    wps = wps > 8 ? 8 : wps < 1 ? 1 : wps;
+    const int b = wps * 4 / (threads / 64);
+    return b < 1 ? 1 : b;
+}
+
+// STATS: y is not written; the (a, b) pairs of the sample's channels go to ab ((samples, C, 2) floats) for a convolution
+// kernel that applies y = swish(x a + b) while it stages its input.
+template <int THREADS, int NV, typename AT, bool STATS = false>
+__global__ __launch_bounds__(THREADS, gn_blocks_per_cu(THREADS, NV, sizeof(AT) == 2)) void bf_gn_fused_bf16_kernel(
+    const AT *__restrict__ x, UpCatSrc uc, int HW, int C, const float *__restrict__ gamma, const float *__restrict__ beta,
+    __bf16 *__restrict__ y, float *__restrict__ ab)
 {
     __shared__ float part[THREADS];
     __shared__ float stat[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Q = C >> 2, Qg = Q >> 3, nq = HW * Q;          // quads per pixel, per group and pixel, per sample
     const int c4 = tid % Q, grp = c4 / Qg;
-    f32x4 v[NV];
+    // bf16 input stays packed in the registers (half as many as float32 values: twice the workgroups per CU, which is what
+    // hides one sample's load -> reduce -> reduce -> store chain behind another's) and is widened at each of its three uses
+    constexpr bool PACKED = sizeof(AT) == 2;
+    using VT = typename std::conditional<PACKED, bf16x4, f32x4>::type;
+    auto raw = [](const AT *p) { return *(const VT *)p; };
+    // (the packed value passes through an empty asm at each use, or the compiler widens once and keeps the float32 copy)
+    auto wide = [](const VT &p) {
+        if constexpr (PACKED) {
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            u32x2 u = __builtin_bit_cast(u32x2, p);
+            asm volatile("" : "+v"(u));
+            return f32x4{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16),
+                         __uint_as_float(u[1] & 0xffff0000u)};
+        } else {
+            return p;
+        }
+    };
+    VT v[NV];
+    const VT zero = {};
     if (uc.up) {
         // a thread's quads are the same four channels of pixels p0, p0 + dp, ...: either all from up or all from skip
         const int Wo = 2 * uc.Wh, dp = THREADS / Q, dy = dp / Wo, dx = dp - dy * Wo;
         const int p0 = tid / Q;
         int py = p0 / Wo, px = p0 - py * Wo;
         const bool from_up = 4 * c4 < uc.Cu;
-        const float *ub = uc.up + (size_t)blockIdx.x * uc.Hh * uc.Wh * uc.Cu + 4 * c4;
-        const float *sb = uc.skip + (size_t)blockIdx.x * HW * uc.Cs + (4 * c4 - uc.Cu);
+        const AT *ub = (const AT *)uc.up + (size_t)blockIdx.x * uc.Hh * uc.Wh * uc.Cu + 4 * c4;
+        const AT *sb = (const AT *)uc.skip + (size_t)blockIdx.x * HW * uc.Cs + (4 * c4 - uc.Cu);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int q = tid + k * THREADS;
-            const float *src = from_up ? ub + (size_t)((py >> 1) * uc.Wh + (px >> 1)) * uc.Cu : sb + (size_t)(py * Wo + px) * uc.Cs;
-            v[k] = q < nq ? *(const f32x4 *)src : f32x4{0.f, 0.f, 0.f, 0.f};
+            const AT *src = from_up ? ub + (size_t)((py >> 1) * uc.Wh + (px >> 1)) * uc.Cu : sb + (size_t)(py * Wo + px) * uc.Cs;
+            v[k] = q < nq ? raw(src) : zero;
             py += dy;
             px += dx;
             if (px >= Wo) { px -= Wo; ++py; }
         }
     } else {
-        const float *xb = x + (size_t)blockIdx.x * HW * C;
+        const AT *xb = x + (size_t)blockIdx.x * HW * C;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int q = tid + k * THREADS;
-            v[k] = q < nq ? *(const f32x4 *)(xb + (size_t)q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            v[k] = q < nq ? raw(xb + (size_t)q * 4) : zero;
         }
     }
     // sum over the threads of each group: wavefront w folds groups w, w + waves, ...; entry e of group g is thread
@@ -224,15 +269,19 @@ __global__ __launch_bounds__(THREADS) void bf_gn_fused_bf16_kernel(const float *
     const float n = (float)(HW * (C >> 3));
     float s = 0.0f;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+    for (int k = 0; k < NV; ++k) {
+        const f32x4 w = wide(v[k]);
+        s += (w[0] + w[1]) + (w[2] + w[3]);
+    }
     const float mean = group_sums(s) / n;
     float qd = 0.0f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         if (tid + k * THREADS < nq) {
+            const f32x4 w = wide(v[k]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float d = v[k][j] - mean;
+                const float d = w[j] - mean;
                 qd = __builtin_fmaf(d, d, qd);
             }
         }
@@ -245,15 +294,24 @@ __global__ __launch_bounds__(THREADS) void bf_gn_fused_bf16_kernel(const float *
         a[j] = inv * gm[j];
         b[j] = bt[j] - mean * a[j];
     }
+    if constexpr (STATS) {
+        if (tid < Q) {
+            float *o = ab + ((size_t)blockIdx.x * C + 4 * c4) * 2;
+            *(f32x4 *)o = f32x4{a[0], b[0], a[1], b[1]};
+            *(f32x4 *)(o + 4) = f32x4{a[2], b[2], a[3], b[3]};
+        }
+        return;
+    }
     __bf16 *yb = y + (size_t)blockIdx.x * HW * C;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int q = tid + k * THREADS;
         if (q < nq) {
+            const f32x4 w = wide(v[k]);
             float r[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float z = __builtin_fmaf(v[k][j], a[j], b[j]);
+                const float z = __builtin_fmaf(w[j], a[j], b[j]);
                 r[j] = z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f));
             }
             *(bf16x4 *)(yb + (size_t)q * 4) = bf16x4{(__bf16)r[0], (__bf16)r[1], (__bf16)r[2], (__bf16)r[3]};
@@ -264,25 +322,34 @@ __global__ __launch_bounds__(THREADS) void bf_gn_fused_bf16_kernel(const float *
 // Launches the fused kernel when a (threads, quads per thread) instance covers the sample; false: the caller takes the
 // two-kernel path.
 template <int THREADS, int NV>
-bool gn_fused_try(const float *x, const UpCatSrc &uc, int64_t B, int HW, int C, const float *gamma, const float *beta, __bf16 *y,
-                  hipStream_t s, bool probe)
+bool gn_fused_try(const void *x, bool a16, const UpCatSrc &uc, int64_t B, int HW, int C, const float *gamma, const float *beta,
+                  __bf16 *y, float *ab, hipStream_t s, bool probe)
 {
     const int Q = C / 4;
     if (THREADS % Q != 0 || (int64_t)HW * Q > (int64_t)THREADS * NV) return false;
-    if (!probe)
-        hipLaunchKernelGGL((bf_gn_fused_bf16_kernel<THREADS, NV>), dim3((unsigned)B), dim3(THREADS), 0, s, x, uc, HW, C, gamma, beta, y);
+    if (probe) return true;
+    if (a16 && ab)
+        hipLaunchKernelGGL((bf_gn_fused_bf16_kernel<THREADS, NV, __bf16, true>), dim3((unsigned)B), dim3(THREADS), 0, s, (const __bf16 *)x,
+                           uc, HW, C, gamma, beta, y, ab);
+    else if (a16)
+        hipLaunchKernelGGL((bf_gn_fused_bf16_kernel<THREADS, NV, __bf16>), dim3((unsigned)B), dim3(THREADS), 0, s, (const __bf16 *)x, uc, HW,
+                           C, gamma, beta, y, ab);
+    else
+        hipLaunchKernelGGL((bf_gn_fused_bf16_kernel<THREADS, NV, float>), dim3((unsigned)B), dim3(THREADS), 0, s, (const float *)x, uc, HW, C,
+                           gamma, beta, y, ab);
     return true;
 }
 
 // probe: only tell whether an instance covers the sample
-bool gn_fused_bf16(const float *x, const UpCatSrc &uc, int64_t B, int HW, int C, const float *gamma, const float *beta, __bf16 *y,
-                   hipStream_t s, bool probe = false)
+// a16: x (or uc's two tensors) holds bf16; ab (a16 only): statistics only, the (a, b) pairs go there and y is not written
+bool gn_fused_bf16(const void *x, bool a16, const UpCatSrc &uc, int64_t B, int HW, int C, const float *gamma, const float *beta,
+                   __bf16 *y, hipStream_t s, bool probe = false, float *ab = nullptr)
 {
     if (C % 32 != 0 || B > 0x7fffffff) return false;   // eight groups of a multiple of four channels
-    return gn_fused_try<256, 4>(x, uc, B, HW, C, gamma, beta, y, s, probe) || gn_fused_try<256, 8>(x, uc, B, HW, C, gamma, beta, y, s, probe) ||
-           gn_fused_try<256, 16>(x, uc, B, HW, C, gamma, beta, y, s, probe) || gn_fused_try<256, 28>(x, uc, B, HW, C, gamma, beta, y, s, probe) ||
-           gn_fused_try<768, 4>(x, uc, B, HW, C, gamma, beta, y, s, probe) || gn_fused_try<768, 13>(x, uc, B, HW, C, gamma, beta, y, s, probe) ||
-           gn_fused_try<768, 25>(x, uc, B, HW, C, gamma, beta, y, s, probe) || gn_fused_try<1024, 20>(x, uc, B, HW, C, gamma, beta, y, s, probe);
+#define IDM_GN_TRY(T, N) gn_fused_try<T, N>(x, a16, uc, B, HW, C, gamma, beta, y, ab, s, probe)
+    return IDM_GN_TRY(256, 4) || IDM_GN_TRY(256, 8) || IDM_GN_TRY(256, 16) || IDM_GN_TRY(256, 28) || IDM_GN_TRY(768, 4) ||
+           IDM_GN_TRY(768, 13) || IDM_GN_TRY(768, 25) || IDM_GN_TRY(1024, 20);
+#undef IDM_GN_TRY
 }
 
 // out = (conv1x1(x) + bias) + h  (the ResBlock's projected shortcut, :188-192); w == nullptr: out = x + h.
@@ -306,28 +373,28 @@ __global__ __launch_bounds__(256) void bf_shortcut_kernel(const float *__restric
 // bf16 convolution mode: the projected shortcut out = (conv1x1(x) + bias) + h on the bf16 matrix cores.  One wavefront =
 // 32 pixels x all output channels; x is read as float32 (eight consecutive channels per lane and step) and rounded to bf16
 // on the way into the MFMA; wpack: bf16 A fragments [c / 16][Cout / 32][lane][8] (the centre tap of the 3x3 packing).
-// HBM-bound: x, h in and out out once each.
-template <int MT>
-__global__ __launch_bounds__(256) void bf_shortcut_mfma_kernel(const float *__restrict__ x, UpCatSrc uc, int Cin,
+// HBM-bound: x, h in and out out once each.  AT = __bf16: x is the operand as it lies in memory, h and out are bf16 too.
+template <int MT, typename AT>
+__global__ __launch_bounds__(256) void bf_shortcut_mfma_kernel(const AT *__restrict__ x, UpCatSrc uc, int Cin,
                                                                const bf16x8 *__restrict__ wpack, const float *__restrict__ bias,
-                                                               const float *__restrict__ hres, float *__restrict__ out, int64_t npix)
+                                                               const AT *__restrict__ hres, AT *__restrict__ out, int64_t npix)
 {
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile * 32 >= npix) return;
     const int64_t p = tile * 32 + li;
     const bool pv = p < npix;
-    const float *xp = x + (pv ? p : 0) * Cin + 8 * h;
+    const AT *xp = x + (pv ? p : 0) * Cin + 8 * h;
     // upsample-concat input (Cu a multiple of 16): channel groups below Cu come from up's pixel (y / 2, x / 2), the others
     // from skip; xs is biased so that xs + c is skip's channel c - Cu
-    const float *xu = nullptr, *xs = nullptr;
+    const AT *xu = nullptr, *xs = nullptr;
     if (uc.up) {
         const int64_t pp = pv ? p : 0;
         const int Wo = 2 * uc.Wh, HWo = 4 * uc.Hh * uc.Wh;
         const int64_t b = pp / HWo;
         const int r = (int)(pp - b * HWo), py = r / Wo, px = r - py * Wo;
-        xu = uc.up + ((b * uc.Hh + (py >> 1)) * uc.Wh + (px >> 1)) * uc.Cu + 8 * h;
-        xs = uc.skip + pp * uc.Cs - uc.Cu + 8 * h;
+        xu = (const AT *)uc.up + ((b * uc.Hh + (py >> 1)) * uc.Wh + (px >> 1)) * uc.Cu + 8 * h;
+        xs = (const AT *)uc.skip + pp * uc.Cs - uc.Cu + 8 * h;
     }
     f32x16 acc[MT];
 #pragma unroll
@@ -336,10 +403,15 @@ __global__ __launch_bounds__(256) void bf_shortcut_mfma_kernel(const float *__re
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
     const int ncg = Cin >> 4;
     for (int cg = 0; cg < ncg; ++cg) {
-        const float *src = !uc.up ? xp + 16 * cg : (16 * cg < uc.Cu ? xu : xs) + 16 * cg;
-        const f32x4 v0 = *(const f32x4 *)src, v1 = *(const f32x4 *)(src + 4);
-        const bf16x8 bv = {(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3],
-                           (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
+        const AT *src = !uc.up ? xp + 16 * cg : (16 * cg < uc.Cu ? xu : xs) + 16 * cg;
+        bf16x8 bv;
+        if constexpr (sizeof(AT) == 4) {
+            const f32x4 v0 = *(const f32x4 *)src, v1 = *(const f32x4 *)(src + 4);
+            bv = bf16x8{(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3],
+                        (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
+        } else {
+            bv = *(const bf16x8 *)src;
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wpack[((size_t)cg * MT + m) * 64 + lane], bv, acc[m], 0, 0, 0);
@@ -351,23 +423,29 @@ __global__ __launch_bounds__(256) void bf_shortcut_mfma_kernel(const float *__re
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int co = m * 32 + 8 * g + 4 * h;
-            const f32x4 b4 = *(const f32x4 *)(bias + co), r4 = *(const f32x4 *)(hres + p * Cout + co);
+            const f32x4 b4 = *(const f32x4 *)(bias + co), r4 = ld4(hres + p * Cout + co);
             const f32x4 z = {acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
-            *(f32x4 *)(out + p * Cout + co) = (z + b4) + r4;
+            st4(out + p * Cout + co, (z + b4) + r4);
         }
 }
 
-__global__ __launch_bounds__(256) void bf_maxpool_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t B,
-                                                         int H, int W, int C)
+// MaxPooling2D(2) (:212, :216): four consecutive channels per thread (C is a multiple of 4)
+template <typename AT>
+__global__ __launch_bounds__(256) void bf_maxpool_kernel(const AT *__restrict__ in, AT *__restrict__ out, int64_t B, int H, int W,
+                                                         int C)
 {
     const int Ho = H >> 1, Wo = W >> 1;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= B * Ho * Wo * C) return;
     const int c = (int)(i % C);
     const int x = (int)((i / C) % Wo), y = (int)((i / ((int64_t)C * Wo)) % Ho);
     const int64_t b = i / ((int64_t)C * Wo * Ho);
-    const float *p = in + ((b * H + 2 * y) * W + 2 * x) * C + c;
-    out[i] = fmaxf(fmaxf(p[0], p[C]), fmaxf(p[(size_t)W * C], p[(size_t)W * C + C]));
+    const AT *p = in + ((b * H + 2 * y) * W + 2 * x) * C + c;
+    const f32x4 v0 = ld4(p), v1 = ld4(p + C), v2 = ld4(p + (size_t)W * C), v3 = ld4(p + (size_t)W * C + C);
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = fmaxf(fmaxf(v0[j], v1[j]), fmaxf(v2[j], v3[j]));
+    st4(out + i, r);
 }
 
 // out (B,2H,2W,Cu+Cs) = Concatenate([UpSampling2D(up), skip]) (:225-226, :230-231)
@@ -386,16 +464,29 @@ __global__ __launch_bounds__(256) void bf_upcat_kernel(const float *__restrict__
 }
 
 // Conv2D(1, kernel 1, sigmoid) (:236)
-__global__ __launch_bounds__(256) void bf_head_kernel(const float *__restrict__ r, const float *__restrict__ w,
+template <typename AT>
+__global__ __launch_bounds__(256) void bf_head_kernel(const AT *__restrict__ r, const float *__restrict__ w,
                                                       const float *__restrict__ bias, float *__restrict__ proba, int64_t npix)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= npix) return;
-    const float *p = r + i * 32;
+    const AT *p = r + i * 32;
     float acc = 0.0f;
-    for (int c = 0; c < 32; ++c) acc = __fmaf_rn(p[c], w[c], acc);
+#pragma unroll
+    for (int c4 = 0; c4 < 32; c4 += 4) {
+        const f32x4 v = ld4(p + c4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __fmaf_rn(v[j], w[c4 + j], acc);
+    }
     acc = __fadd_rn(acc, bias[0]);
     proba[i] = __fdiv_rn(1.0f, __fadd_rn(1.0f, cexp(-acc)));
+}
+
+// bf16 activations handed out as float32 (the optional ResBlock outputs of a forward call)
+__global__ __launch_bounds__(256) void bf_widen_kernel(const __bf16 *__restrict__ in, float *__restrict__ out, int64_t n)
+{
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i < n) st4(out + i, ld4(in + i));
 }
 
 // X ^= (u < p) (:49-50).  One thread per four pixels; u from the injected tensor or from
@@ -525,11 +616,11 @@ int time_vectors(idm_bitflip *m, const float *emb_host, int rows, hipStream_t s)
     return IDM_OK;
 }
 
-// y: float32, or bf16 in the same buffer when `half`
+// y: float32, or bf16 in the same buffer when `half`; a16 (bf16 mode only): x holds bf16
 void gn_silu(const float *x, int64_t B, int HW, int C, const float *gamma, const float *beta, float *ab, float *y, bool half,
-             hipStream_t s, const UpCatSrc &uc = UpCatSrc{})
+             hipStream_t s, const UpCatSrc &uc = UpCatSrc{}, bool a16 = false)
 {
-    if (half && gn_fused_bf16(x, uc, B, HW, C, gamma, beta, (__bf16 *)y, s)) return;
+    if (half && gn_fused_bf16(x, a16, uc, B, HW, C, gamma, beta, (__bf16 *)y, s)) return;
     hipLaunchKernelGGL(bf_gn_stats_kernel, dim3((unsigned)((B * 8 + 3) / 4)), dim3(256), 0, s, x, B, HW, C, gamma, beta, ab);
     const int64_t n = B * HW * C;
     if (half)
@@ -542,13 +633,14 @@ void gn_silu(const float *x, int64_t B, int HW, int C, const float *gamma, const
 // resid / res_out (bf16 mode only, may be null): when the LDS-tiled kernel covers the shape it writes
 // res_out = (conv + bias) + resid instead of out and the function returns true (the block's identity shortcut rides in the
 // convolution's epilogue); false: out holds the plain convolution.
+// a16 (bf16 mode on shapes the LDS-tiled kernel covers): out, resid and res_out hold bf16.
 bool conv3(const float *in, int64_t B, int H, int W, int Cin, const void *wpack, const float *bias, const float *tadd,
-           float *out, int Cout, bool half, hipStream_t s, const float *resid = nullptr, float *res_out = nullptr)
+           float *out, int Cout, bool half, hipStream_t s, const float *resid = nullptr, float *res_out = nullptr, bool a16 = false)
 {
     ConvArgs a = {};
     a.in0 = in; a.in1 = nullptr; a.C0 = Cin; a.C1 = 0; a.H = H; a.W = W; a.B = B; a.wpack = wpack; a.bias = bias;
     a.scale = nullptr; a.shift = nullptr; a.tadd = tadd; a.out = out; a.Cout = Cout; a.mode = CONV_PLAIN; a.silu = 0;
-    a.out_f32 = 1;
+    a.out_f32 = 1; a.io_bf16 = a16;
     if (!half) { launch_conv_f32(a, s); return false; }
     if (resid && res_out) {
         a.resid = resid; a.out = res_out;
@@ -559,12 +651,57 @@ bool conv3(const float *in, int64_t B, int H, int W, int Cin, const void *wpack,
     return false;
 }
 
+template <typename AT>
+void shortcut_mfma(int mt, const void *x, const UpCatSrc &uc, int Cin, const bf16x8 *wp, const float *sb, const void *h, void *out,
+                   int64_t npix, hipStream_t s)
+{
+    const unsigned grid = (unsigned)((npix + 127) / 128);
+#define IDM_SC(M) hipLaunchKernelGGL((bf_shortcut_mfma_kernel<M, AT>), dim3(grid), dim3(256), 0, s, (const AT *)x, uc, Cin, wp, sb, (const AT *)h, (AT *)out, npix)
+    switch (mt) {
+    case 1: IDM_SC(1); break;
+    case 2: IDM_SC(2); break;
+    case 3: IDM_SC(3); break;
+    default: IDM_SC(4); break;
+    }
+#undef IDM_SC
+}
+
+// The ResBlock on bf16 activations with both GroupNorms folded into the convolutions: a statistics kernel leaves the (a, b)
+// pairs of every (sample, channel), the convolution applies y = swish(x a + b) while it stages its tiles, so the normalised
+// tensors never go through memory.  uc.up == nullptr: the input is the plain tensor x.  false (an instance is missing):
+// nothing useful was written, the caller runs the unfolded kernels.
+bool resblock_act16(idm_bitflip *m, int i, const float *x, const UpCatSrc &uc, int64_t B, int H, int W, const float *tvec, float *out,
+                    float *tbuf, float *ab, hipStream_t s)
+{
+    const int Cin = kCin[i], Cw = kWidth[i], HW = H * W;
+    auto folded = [&](const void *up, int Cu, const void *full, int Cf, const void *wpack, const float *bias, const float *tadd,
+                      const float *resid, float *dst) {
+        ConvArgs a = {};
+        a.in0 = up; a.in1 = full; a.C0 = Cu; a.C1 = Cf; a.H = H; a.W = W; a.B = B; a.wpack = wpack; a.bias = bias; a.tadd = tadd;
+        a.out = dst; a.Cout = Cw; a.mode = CONV_UPCAT; a.out_f32 = 1; a.io_bf16 = 1; a.gn_ab = ab; a.resid = resid;
+        return launch_conv_tile_bf16(a, s);
+    };
+    if (!gn_fused_bf16(x, true, uc, B, HW, Cin, m->t[tb(i, K_G1_G)], m->t[tb(i, K_G1_B)], nullptr, s, false, ab)) return false;
+    if (!(uc.up ? folded(uc.up, uc.Cu, uc.skip, uc.Cs, m->c1_pack16[i], m->t[tb(i, K_C1_B)], tvec, nullptr, tbuf)
+                : folded(nullptr, 0, x, Cin, m->c1_pack16[i], m->t[tb(i, K_C1_B)], tvec, nullptr, tbuf)))
+        return false;
+    if (!gn_fused_bf16(tbuf, true, UpCatSrc{}, B, HW, Cw, m->t[tb(i, K_G2_G)], m->t[tb(i, K_G2_B)], nullptr, s, false, ab)) return false;
+    const bool identity = !m->s_pack16[i];
+    // conv2 reads tbuf and, with a projected shortcut, writes it too: in place is safe only per workgroup, so that case
+    // goes through `out` and the shortcut kernel adds in place there instead
+    if (identity) return folded(nullptr, 0, tbuf, Cw, m->c2_pack16[i], m->t[tb(i, K_C2_B)], nullptr, x, out);
+    if (!folded(nullptr, 0, tbuf, Cw, m->c2_pack16[i], m->t[tb(i, K_C2_B)], nullptr, nullptr, out)) return false;
+    shortcut_mfma<__bf16>(Cw / 32, x, uc, Cin, (const bf16x8 *)m->s_pack16[i], m->t[tb(i, K_S_B)], out, out, B * HW, s);
+    return true;
+}
+
 // ResBlock (:168-193).  ta: >= B*H*W*max(Cin,width) floats, tbuf: >= B*H*W*width floats.
 // cat (optional): x = Concatenate([UpSampling2D(cat->up), cat->skip]).  In the bf16 mode the block's two readers of x (the
 // first GroupNorm and the projected shortcut) read the two tensors in place when their fused kernels cover the shape;
 // otherwise the concatenation is first written to x.
+// a16 (only where act16_covers() holds: every fused kernel covers the shape): x, tbuf and out hold bf16.
 void resblock(idm_bitflip *m, int i, float *x, int64_t B, int H, int W, const float *tvec, float *out, float *ta,
-              float *tbuf, float *ab, hipStream_t s, const UpCatSrc *cat = nullptr)
+              float *tbuf, float *ab, hipStream_t s, const UpCatSrc *cat = nullptr, bool a16 = false)
 {
     const int Cin = kCin[i], Cw = kWidth[i], HW = H * W;
     const bool half = m->precision == IDM_BF16;
@@ -572,31 +709,27 @@ void resblock(idm_bitflip *m, int i, float *x, int64_t B, int H, int W, const fl
     UpCatSrc uc = {};
     if (cat) {
         const bool in_place = mfma_shortcut && cat->Cu % 16 == 0 && cat->Cs % 4 == 0 &&
-                              gn_fused_bf16(nullptr, *cat, B, HW, Cin, nullptr, nullptr, nullptr, s, true);
+                              gn_fused_bf16(nullptr, a16, *cat, B, HW, Cin, nullptr, nullptr, nullptr, s, true);
         if (in_place) uc = *cat;
         else
-            hipLaunchKernelGGL(bf_upcat_kernel, dim3(blocks(B * HW * Cin / 4)), dim3(256), 0, s, cat->up, cat->skip, x, B, cat->Hh,
-                               cat->Wh, cat->Cu, cat->Cs);
+            hipLaunchKernelGGL(bf_upcat_kernel, dim3(blocks(B * HW * Cin / 4)), dim3(256), 0, s, (const float *)cat->up,
+                               (const float *)cat->skip, x, B, cat->Hh, cat->Wh, cat->Cu, cat->Cs);
     }
-    gn_silu(x, B, HW, Cin, m->t[tb(i, K_G1_G)], m->t[tb(i, K_G1_B)], ab, ta, half, s, uc);
-    conv3(ta, B, H, W, Cin, half ? m->c1_pack16[i] : m->c1_pack[i], m->t[tb(i, K_C1_B)], tvec, tbuf, Cw, half, s);
-    gn_silu(tbuf, B, HW, Cw, m->t[tb(i, K_G2_G)], m->t[tb(i, K_G2_B)], ab, ta, half, s);
+    if (a16 && resblock_act16(m, i, x, uc, B, H, W, tvec, out, tbuf, ab, s)) return;
+    gn_silu(x, B, HW, Cin, m->t[tb(i, K_G1_G)], m->t[tb(i, K_G1_B)], ab, ta, half, s, uc, a16);
+    conv3(ta, B, H, W, Cin, half ? m->c1_pack16[i] : m->c1_pack[i], m->t[tb(i, K_C1_B)], tvec, tbuf, Cw, half, s, nullptr, nullptr, a16);
+    gn_silu(tbuf, B, HW, Cw, m->t[tb(i, K_G2_G)], m->t[tb(i, K_G2_B)], ab, ta, half, s, UpCatSrc{}, a16);
     // identity shortcut (Cin == width, :188-192 take the other branch): out = x + h, in the bf16 mode inside the convolution
     const bool identity = !m->s_pack[i] && !(half && m->s_pack16[i]);
     if (conv3(ta, B, H, W, Cw, half ? m->c2_pack16[i] : m->c2_pack[i], m->t[tb(i, K_C2_B)], nullptr, tbuf, Cw, half, s,
-              half && identity ? x : nullptr, out))
+              half && identity ? x : nullptr, out, a16))
         return;
     const int64_t npix = B * HW;
     if (mfma_shortcut) {
-        const unsigned grid = (unsigned)((npix + 127) / 128);
         const bf16x8 *wp = (const bf16x8 *)m->s_pack16[i];
         const float *sb = m->t[tb(i, K_S_B)];
-        switch (Cw / 32) {
-        case 1: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<1>, dim3(grid), dim3(256), 0, s, (const float *)x, uc, Cin, wp, sb, (const float *)tbuf, out, npix); break;
-        case 2: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<2>, dim3(grid), dim3(256), 0, s, (const float *)x, uc, Cin, wp, sb, (const float *)tbuf, out, npix); break;
-        case 3: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<3>, dim3(grid), dim3(256), 0, s, (const float *)x, uc, Cin, wp, sb, (const float *)tbuf, out, npix); break;
-        default: hipLaunchKernelGGL(bf_shortcut_mfma_kernel<4>, dim3(grid), dim3(256), 0, s, (const float *)x, uc, Cin, wp, sb, (const float *)tbuf, out, npix); break;
-        }
+        if (a16) shortcut_mfma<__bf16>(Cw / 32, x, uc, Cin, wp, sb, tbuf, out, npix, s);
+        else shortcut_mfma<float>(Cw / 32, x, uc, Cin, wp, sb, tbuf, out, npix, s);
     } else if (m->s_pack[i]) {
         // projected shortcut (:188-192) on the matrix cores: the centre tap alone is a 1x1 convolution with the
         // same k-ordered chain; out = (chain + bias) + h
@@ -611,12 +744,32 @@ void resblock(idm_bitflip *m, int i, float *x, int64_t B, int H, int W, const fl
     }
 }
 
+// bf16 mode: may the activations between the kernels be bf16?  Only where no fallback kernel (two-pass GroupNorm, written-out
+// concatenation, per-layer convolution, scalar shortcut: all float32 in, float32 out) would run: maps at most 32 wide for the
+// LDS-tiled convolution at all three levels, a one-workgroup GroupNorm instance for every (pixels, channels) pair, and the
+// MFMA kernel for every projected shortcut.  ISINGDIFF_BITFLIP_ACT=f32 keeps float32 activations (comparison runs).
+bool act16_covers(const idm_bitflip *m, int64_t B, int H, int W)
+{
+    static const bool off = [] { const char *e = getenv("ISINGDIFF_BITFLIP_ACT"); return e && !strcmp(e, "f32"); }();
+    if (off || m->precision != IDM_BF16 || W > 32 || W < 16 || H < 4) return false;
+    for (int i = 0; i < NBLK; ++i) {
+        const int sh = (i == 0 || i == 4) ? 0 : (i == 2 ? 2 : 1), HW = (H >> sh) * (W >> sh);
+        if (!gn_fused_bf16(nullptr, true, UpCatSrc{}, B, HW, kCin[i], nullptr, nullptr, nullptr, nullptr, true) ||
+            !gn_fused_bf16(nullptr, true, UpCatSrc{}, B, HW, kWidth[i], nullptr, nullptr, nullptr, nullptr, true))
+            return false;
+        if (kCin[i] != kWidth[i] && !(m->s_pack16[i] && kWidth[i] % 32 == 0 && kWidth[i] <= 128 && kCin[i] % 16 == 0)) return false;
+    }
+    return true;
+}
+
 // Forward of Bc samples; tvec: this step's five time vectors (device); proba (Bc,H,W).
 int forward_chunk(idm_bitflip *m, const uint8_t *x, const float *tvec, float *proba, int64_t Bc, int H, int W,
                   float *const *taps, int64_t tap_off, hipStream_t s)
 {
     const size_t hw = (size_t)H * W;
+    const bool a16 = act16_covers(m, Bc, H, W);
     float *p = (float *)m->ws;
+    // (with bf16 activations every buffer but ta uses half of its float32 size)
     auto take = [&](size_t per) { float *q = p; p += per * Bc; return q; };
     float *x0 = take(hw * 32), *r0 = take(hw * 32), *r1 = take(hw * 16), *r2 = take(hw * 8), *cat = take(hw * 96),
           *ta = take(hw * 96), *tbuf = take(hw * 32), *pl = take(hw * 8), *d3 = take(hw * 16), *d4 = take(hw * 32);
@@ -625,25 +778,43 @@ int forward_chunk(idm_bitflip *m, const uint8_t *x, const float *tvec, float *pr
     const float *tv[NBLK];
     int o = 0;
     for (int i = 0; i < NBLK; ++i) { tv[i] = tvec + o; o += kWidth[i]; }
-    hipLaunchKernelGGL(bf_in_kernel, dim3(blocks(Bc * hw * 32)), dim3(256), 0, s, x, m->t[T_IN_W], m->t[T_IN_B], x0,
-                       (int64_t)(Bc * hw));
-    resblock(m, 0, x0, Bc, H, W, tv[0], r0, ta, tbuf, ab, s);
-    hipLaunchKernelGGL(bf_maxpool_kernel, dim3(blocks(Bc * hw * 8)), dim3(256), 0, s, (const float *)r0, pl, Bc, H, W, 32);
-    resblock(m, 1, pl, Bc, H2, W2, tv[1], r1, ta, tbuf, ab, s);
-    hipLaunchKernelGGL(bf_maxpool_kernel, dim3(blocks(Bc * hw * 4)), dim3(256), 0, s, (const float *)r1, pl, Bc, H2, W2, 64);
-    resblock(m, 2, pl, Bc, H4, W4, tv[2], r2, ta, tbuf, ab, s);
+    if (a16)
+        hipLaunchKernelGGL(bf_in_kernel<__bf16>, dim3(blocks(Bc * hw * 32)), dim3(256), 0, s, x, m->t[T_IN_W], m->t[T_IN_B], (__bf16 *)x0,
+                           (int64_t)(Bc * hw));
+    else
+        hipLaunchKernelGGL(bf_in_kernel<float>, dim3(blocks(Bc * hw * 32)), dim3(256), 0, s, x, m->t[T_IN_W], m->t[T_IN_B], x0,
+                           (int64_t)(Bc * hw));
+    auto maxpool = [&](const float *in, float *out, int h, int w, int C) {
+        const unsigned grid = blocks(Bc * (int64_t)(h / 2) * (w / 2) * C / 4);
+        if (a16) hipLaunchKernelGGL(bf_maxpool_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16 *)in, (__bf16 *)out, Bc, h, w, C);
+        else hipLaunchKernelGGL(bf_maxpool_kernel<float>, dim3(grid), dim3(256), 0, s, in, out, Bc, h, w, C);
+    };
+    resblock(m, 0, x0, Bc, H, W, tv[0], r0, ta, tbuf, ab, s, nullptr, a16);
+    maxpool(r0, pl, H, W, 32);
+    resblock(m, 1, pl, Bc, H2, W2, tv[1], r1, ta, tbuf, ab, s, nullptr, a16);
+    maxpool(r1, pl, H2, W2, 64);
+    resblock(m, 2, pl, Bc, H4, W4, tv[2], r2, ta, tbuf, ab, s, nullptr, a16);
     const UpCatSrc cat3 = {r2, r1, H4, W4, 128, 64}, cat4 = {d3, r0, H2, W2, 64, 32};
-    resblock(m, 3, cat, Bc, H2, W2, tv[3], d3, ta, tbuf, ab, s, &cat3);
-    resblock(m, 4, cat, Bc, H, W, tv[4], d4, ta, tbuf, ab, s, &cat4);
-    hipLaunchKernelGGL(bf_head_kernel, dim3(blocks(Bc * hw)), dim3(256), 0, s, (const float *)d4, m->t[T_OUT_W],
-                       m->t[T_OUT_B], proba, (int64_t)(Bc * hw));
+    resblock(m, 3, cat, Bc, H2, W2, tv[3], d3, ta, tbuf, ab, s, &cat3, a16);
+    resblock(m, 4, cat, Bc, H, W, tv[4], d4, ta, tbuf, ab, s, &cat4, a16);
+    if (a16)
+        hipLaunchKernelGGL(bf_head_kernel<__bf16>, dim3(blocks(Bc * hw)), dim3(256), 0, s, (const __bf16 *)d4, m->t[T_OUT_W], m->t[T_OUT_B],
+                           proba, (int64_t)(Bc * hw));
+    else
+        hipLaunchKernelGGL(bf_head_kernel<float>, dim3(blocks(Bc * hw)), dim3(256), 0, s, (const float *)d4, m->t[T_OUT_W], m->t[T_OUT_B],
+                           proba, (int64_t)(Bc * hw));
     if (taps) {
         const float *src[NBLK] = {r0, r1, r2, d3, d4};
         const size_t per[NBLK] = {hw * 32, hw * 16, hw * 8, hw * 16, hw * 32};
-        for (int i = 0; i < NBLK; ++i)
-            if (taps[i])
-                BFCHK(hipMemcpyAsync(taps[i] + (size_t)tap_off * per[i], src[i], per[i] * Bc * sizeof(float),
-                                     hipMemcpyDeviceToDevice, s));
+        for (int i = 0; i < NBLK; ++i) {
+            if (!taps[i]) continue;
+            float *dst = taps[i] + (size_t)tap_off * per[i];
+            if (a16)
+                hipLaunchKernelGGL(bf_widen_kernel, dim3(blocks((int64_t)(per[i] * Bc / 4))), dim3(256), 0, s, (const __bf16 *)src[i], dst,
+                                   (int64_t)(per[i] * Bc));
+            else
+                BFCHK(hipMemcpyAsync(dst, src[i], per[i] * Bc * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
     }
     BFCHK(hipGetLastError());
     return IDM_OK;

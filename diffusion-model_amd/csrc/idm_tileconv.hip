@@ -4,19 +4,29 @@
 // sum; mnist_diffusion/mnist_diffusion.py:168-193), on the sliding-window MFMA stage the Ising kernels use: a workgroup
 // stages R + 2 rows of one sample in LDS ([row][col][channel], zero halo), its four wavefronts split the R output rows
 // (or, for maps narrower than 32, the 32-pixel groups of several rows) and each MFMA tile's accumulators leave as
-// float32, 16 bytes per lane and channel quad.  One workgroup per (sample, band); weights come from L2 through the
-// stage's register ring.
+// float32, 16 bytes per lane and channel quad - or, with ConvArgs::io_bf16, rounded once to bf16 (and the residual read as
+// bf16): the sampler keeps its activations in bf16 between kernels then.  One workgroup per (sample, band); weights come
+// from L2 through the stage's register ring.
+// GNUP instances take the ResBlock's input as it is before its first GroupNorm, x = Concatenate([UpSampling2D(up), skip])
+// (:225-226, :230-231) in bf16, and apply y = swish(x a + b) with the (a, b) pairs of the sample's channels (ConvArgs::gn_ab)
+// while they stage the tile: the normalised tensor never goes through memory.
 #include "idm_conv_stage.h"
 
 #include <algorithm>
 
 namespace {
 
-template <int CA, int COUT, int NT, int MS, int WD, int NP>
+struct GnUpSrc {
+    const __bf16 *skip;   // (B, H, W, CA - Cu); the kernel's `in` is up, (B, H / 2, W / 2, Cu)
+    const float *ab;      // (B, CA, 2)
+    int Cu;
+};
+
+template <int CA, int COUT, int NT, int MS, int WD, int NP, typename OT, bool GNUP = false>
 __global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__restrict__ in, const bf16x8 *__restrict__ w,
                                                               const float *__restrict__ bias, const float *__restrict__ tadd,
-                                                              const float *__restrict__ resid, float *__restrict__ out, int H,
-                                                              int W, int R, int nbands)
+                                                              const OT *__restrict__ resid, OT *__restrict__ out, int H,
+                                                              int W, int R, int nbands, GnUpSrc gu)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SA = CA * 2 + 16;
@@ -30,17 +40,62 @@ __global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__r
         cst[i] = bias[i];
         cst[COUT + i] = tadd ? tadd[i] : 0.0f;
     }
-    TileRegs<CA, NP, 256> regs;
-    regs.load(in + (size_t)b * H * W * CA, H, W, y0 - 1, rows + 2, tid);
-    regs.store(tile, W, rows + 2, tid);
+    if constexpr (GNUP) {
+        constexpr int CH = CA / 8, U = 4;
+        float *abt = cst + 2 * COUT;
+        for (int i = tid; i < 2 * CA; i += 256) abt[i] = gu.ab[(size_t)b * 2 * CA + i];
+        __syncthreads();
+        const int Cu = gu.Cu, Cs = CA - Cu, Hh = H >> 1, Wh = W >> 1, ipr = W * CH, total = (rows + 2) * ipr;
+        const __bf16 *ub = in + (size_t)b * Hh * Wh * Cu, *sb = gu.skip + (size_t)b * H * W * Cs;
+        bf16x8 zero;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zero[j] = (__bf16)0.0f;
+        // items (tile row, column, eight channels), U per thread in flight
+        for (int i0 = tid; i0 < total; i0 += 256 * U) {
+            bf16x8 raw[U];
+            int dst[U], ch8[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * 256;
+                const int t = i / ipr, rem = i - t * ipr, xc = rem / CH, ch = rem - xc * CH, gy = y0 - 1 + t;
+                const bool live = i < total && gy >= 0 && gy < H;
+                const __bf16 *src = 8 * ch < Cu ? ub + (size_t)((gy >> 1) * Wh + (xc >> 1)) * Cu + 8 * ch
+                                                : sb + (size_t)(gy * W + xc) * Cs + (8 * ch - Cu);
+                raw[u] = live ? *(const bf16x8 *)src : zero;
+                dst[u] = i < total ? (t * (W + 2) + xc + 1) * SA + ch * 16 : -1;
+                ch8[u] = live ? 8 * ch : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (dst[u] < 0) continue;
+                bf16x8 o = zero;
+                if (ch8[u] >= 0) {
+                    const float *abp = abt + 2 * ch8[u];
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const f32x4 k = *(const f32x4 *)(abp + 2 * j);   // a, b of channels j and j + 1
+                        const float z0 = __builtin_fmaf((float)raw[u][j], k[0], k[1]), z1 = __builtin_fmaf((float)raw[u][j + 1], k[2], k[3]);
+                        o[j] = (__bf16)(z0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z0 * -1.4426950408889634f)));
+                        o[j + 1] = (__bf16)(z1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z1 * -1.4426950408889634f)));
+                    }
+                }
+                *(bf16x8 *)(tile + dst[u]) = o;
+            }
+        }
+        clear_halo<CA, 256>(tile, W, rows + 2, 0, 0, tid);
+    } else {
+        TileRegs<CA, NP, 256> regs;
+        regs.load(in + (size_t)b * H * W * CA, H, W, y0 - 1, rows + 2, tid);
+        regs.store(tile, W, rows + 2, tid);
+    }
     using Conv = ConvStage<CA, 0, false, COUT, NT, MS, WD, true>;
     Conv cs;
     const LaneGeo geo = make_geo(W, lane & 31);
     cs.begin(tile, nullptr, cst, cst + COUT, geo, 0, rows, w, wave, lane);
     __syncthreads();
-    float *ob = out + ((size_t)b * H + y0) * W * COUT;
+    OT *ob = out + ((size_t)b * H + y0) * W * COUT;
     // resid (same shape as out, may be null): added last, out = (conv + bias + vector) + resid - a ResBlock's identity shortcut
-    const float *rb = resid ? resid + ((size_t)b * H + y0) * W * COUT : nullptr;
+    const OT *rb = resid ? resid + ((size_t)b * H + y0) * W * COUT : nullptr;
     cs.run([&](const f32x16 &acc, const f32x4 *, const f32x4 *kt, int mt, int r, int x, bool valid) {
         if (!valid) return;
         const size_t o = ((size_t)r * W + x) * COUT + mt * 32 + 4 * h;
@@ -48,21 +103,30 @@ __global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__r
         for (int g = 0; g < 4; ++g) {
             f32x4 z = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
             z = z + kt[g];
-            if (rb) z = z + *(const f32x4 *)(rb + o + 8 * g);
-            *(f32x4 *)(ob + o + 8 * g) = z;
+            if constexpr (sizeof(OT) == 4) {
+                if (rb) z = z + *(const f32x4 *)(rb + o + 8 * g);
+                *(f32x4 *)(ob + o + 8 * g) = z;
+            } else {
+                if (rb) {
+                    const bf16x4 r4 = *(const bf16x4 *)(rb + o + 8 * g);
+                    z = z + f32x4{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
+                }
+                *(bf16x4 *)(ob + o + 8 * g) = pack4(z[0], z[1], z[2], z[3]);
+            }
         }
     });
 }
 
-template <int CA, int COUT, int NT, int MS, int WD, int NP>
-bool launch_tile(const ConvArgs &a, hipStream_t s)
+template <int CA, int COUT, int NT, int MS, int WD, int NP, typename OT, bool GNUP = false>
+bool launch_tile_as(const ConvArgs &a, hipStream_t s)
 {
     static_assert(BIAS_IN_ACC, "the epilogue expects the bias in the accumulators");
     constexpr int SA = CA * 2 + 16;
     // the tallest band whose tile fits NP x 256 staged items and 76 KB of LDS (two workgroups per CU)
     int nb = 1, R = a.H;
     auto fits = [&](int r) {
-        return (int64_t)(r + 2) * a.W * (CA / 8) <= (int64_t)NP * 256 && (r + 2) * (a.W + 2) * SA + 2 * COUT * 4 + 16 <= 76 * 1024;
+        return (GNUP || (int64_t)(r + 2) * a.W * (CA / 8) <= (int64_t)NP * 256) &&
+               (r + 2) * (a.W + 2) * SA + 2 * COUT * 4 + (GNUP ? 2 * CA * 4 : 0) + 16 <= 76 * 1024;
     };
     while (!fits(R)) {
         if (R == 1) return false;
@@ -71,8 +135,8 @@ bool launch_tile(const ConvArgs &a, hipStream_t s)
     }
     nb = (a.H + R - 1) / R;
     if (a.B * nb > 0x7fffffff) return false;
-    const int lds = (((R + 2) * (a.W + 2) * SA + 15) & ~15) + 2 * COUT * 4;
-    auto kernel = tile_conv_f32out_kernel<CA, COUT, NT, MS, WD, NP>;
+    const int lds = (((R + 2) * (a.W + 2) * SA + 15) & ~15) + 2 * COUT * 4 + (GNUP ? 2 * CA * 4 : 0);
+    auto kernel = tile_conv_f32out_kernel<CA, COUT, NT, MS, WD, NP, OT, GNUP>;
     static thread_local bool configured[IDM_MAX_DEVICES] = {};
     const int slot = idm_device_slot();
     if (slot < 0) return false;
@@ -81,8 +145,15 @@ bool launch_tile(const ConvArgs &a, hipStream_t s)
         configured[slot] = true;
     }
     hipLaunchKernelGGL(kernel, dim3((unsigned)(a.B * nb)), dim3(256), lds, s, (const __bf16 *)a.in0, (const bf16x8 *)a.wpack, a.bias,
-                       a.tadd, a.resid, (float *)a.out, a.H, a.W, R, nb);
+                       a.tadd, (const OT *)a.resid, (OT *)a.out, a.H, a.W, R, nb,
+                       GnUpSrc{(const __bf16 *)a.in1, a.gn_ab, a.C0});
     return true;
+}
+
+template <int CA, int COUT, int NT, int MS, int WD, int NP>
+bool launch_tile(const ConvArgs &a, hipStream_t s)
+{
+    return a.io_bf16 ? launch_tile_as<CA, COUT, NT, MS, WD, NP, __bf16>(a, s) : launch_tile_as<CA, COUT, NT, MS, WD, NP, float>(a, s);
 }
 
 }  // namespace
@@ -90,6 +161,20 @@ bool launch_tile(const ConvArgs &a, hipStream_t s)
 // true: launched.  false: shape not covered (the caller falls back to the per-layer kernel).
 bool launch_conv_tile_bf16(const ConvArgs &a, hipStream_t s)
 {
+    if (a.mode == CONV_UPCAT && a.gn_ab && a.io_bf16 && !a.silu && a.out_f32 && !a.scale && a.W <= 32 && a.W >= 4 && a.H >= 1 &&
+        a.C0 % 8 == 0 && (a.C0 == 0 || !((a.W | a.H) & 1))) {
+        // (C0 = 0: a plain tensor in in1)
+        const int ci = a.C0 + a.C1, co = a.Cout;
+        if (ci == 32 && co == 32) return launch_tile_as<32, 32, 3, 1, 2, 14, __bf16, true>(a, s);
+        if (ci == 32 && co == 64) return launch_tile_as<32, 64, 2, 2, 2, 14, __bf16, true>(a, s);
+        if (ci == 64 && co == 64) return launch_tile_as<64, 64, 2, 2, 2, 14, __bf16, true>(a, s);
+        if (ci == 64 && co == 128) return launch_tile_as<64, 128, 2, 2, 2, 14, __bf16, true>(a, s);
+        if (ci == 128 && co == 128) return launch_tile_as<128, 128, 2, 2, 2, 14, __bf16, true>(a, s);
+        if (ci == 192 && co == 64) return launch_tile_as<192, 64, 2, 2, 2, 24, __bf16, true>(a, s);
+        if (ci == 96 && co == 32) return launch_tile_as<96, 32, 3, 1, 2, 24, __bf16, true>(a, s);
+        return false;
+    }
+    if (a.gn_ab) return false;
     if (a.mode != CONV_PLAIN || a.C1 != 0 || a.silu || !a.out_f32 || a.scale || a.W > 32 || a.W < 4 || a.H < 1) return false;
     const int ci = a.C0, co = a.Cout;
     if (ci == 32 && co == 32) return launch_tile<32, 32, 3, 1, 2, 14>(a, s);

@@ -88,10 +88,16 @@ template <typename AT>
 __global__ __launch_bounds__(256) void bf_in_kernel(const uint8_t *__restrict__ x, const float *__restrict__ w,
                                                     const float *__restrict__ b, AT *__restrict__ out, int64_t npix)
 {
+    // four consecutive channels per thread
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npix * 32) return;
-    const int c = (int)(i & 31);
-    out[i] = (AT)__fadd_rn(__fmaf_rn((float)x[i >> 5], w[c], 0.0f), b[c]);
+    if (i >= npix * 8) return;
+    const int c = (int)(i & 7) * 4;
+    const float xv = (float)x[i >> 3];
+    const f32x4 w4 = *(const f32x4 *)(w + c), b4 = *(const f32x4 *)(b + c);
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = __fadd_rn(__fmaf_rn(xv, w4[j], 0.0f), b4[j]);
+    st4(out + i * 4, r);
 }
 
 // GroupNormalization(groups=8) statistics: one wavefront per (sample, group); writes the affine
@@ -779,10 +785,10 @@ int forward_chunk(idm_bitflip *m, const uint8_t *x, const float *tvec, float *pr
     int o = 0;
     for (int i = 0; i < NBLK; ++i) { tv[i] = tvec + o; o += kWidth[i]; }
     if (a16)
-        hipLaunchKernelGGL(bf_in_kernel<__bf16>, dim3(blocks(Bc * hw * 32)), dim3(256), 0, s, x, m->t[T_IN_W], m->t[T_IN_B], (__bf16 *)x0,
+        hipLaunchKernelGGL(bf_in_kernel<__bf16>, dim3(blocks(Bc * hw * 8)), dim3(256), 0, s, x, m->t[T_IN_W], m->t[T_IN_B], (__bf16 *)x0,
                            (int64_t)(Bc * hw));
     else
-        hipLaunchKernelGGL(bf_in_kernel<float>, dim3(blocks(Bc * hw * 32)), dim3(256), 0, s, x, m->t[T_IN_W], m->t[T_IN_B], x0,
+        hipLaunchKernelGGL(bf_in_kernel<float>, dim3(blocks(Bc * hw * 8)), dim3(256), 0, s, x, m->t[T_IN_W], m->t[T_IN_B], x0,
                            (int64_t)(Bc * hw));
     auto maxpool = [&](const float *in, float *out, int h, int w, int C) {
         const unsigned grid = blocks(Bc * (int64_t)(h / 2) * (w / 2) * C / 4);

@@ -41,45 +41,59 @@ __global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__r
         cst[COUT + i] = tadd ? tadd[i] : 0.0f;
     }
     if constexpr (GNUP) {
-        constexpr int CH = CA / 8, U = 4;
-        float *abt = cst + 2 * COUT;
-        for (int i = tid; i < 2 * CA; i += 256) abt[i] = gu.ab[(size_t)b * 2 * CA + i];
-        __syncthreads();
+        constexpr int CH = CA / 8;
         const int Cu = gu.Cu, Cs = CA - Cu, Hh = H >> 1, Wh = W >> 1, ipr = W * CH, total = (rows + 2) * ipr;
         const __bf16 *ub = in + (size_t)b * Hh * Wh * Cu, *sb = gu.skip + (size_t)b * H * W * Cs;
         bf16x8 zero;
 #pragma unroll
         for (int j = 0; j < 8; ++j) zero[j] = (__bf16)0.0f;
-        // items (tile row, column, eight channels), U per thread in flight
-        for (int i0 = tid; i0 < total; i0 += 256 * U) {
+        // items (tile row, column, eight channels), in rounds of U per thread: a round's loads are all in flight before its
+        // first item is used (all NP at once would cost the 24-item instances their second workgroup per CU)
+        constexpr int U = 8;
+        auto item = [&](int i, int &t, int &xc, int &ch) {
+            t = i / ipr;
+            const int rem = i - t * ipr;
+            xc = rem / CH;
+            ch = rem - xc * CH;
+        };
+        float *abt = cst + 2 * COUT;
+        for (int i = tid; i < 2 * CA; i += 256) abt[i] = gu.ab[(size_t)b * 2 * CA + i];
+        bool synced = false;
+#pragma unroll
+        for (int k0 = 0; k0 < NP; k0 += U) {
             bf16x8 raw[U];
-            int dst[U], ch8[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int i = i0 + u * 256;
-                const int t = i / ipr, rem = i - t * ipr, xc = rem / CH, ch = rem - xc * CH, gy = y0 - 1 + t;
-                const bool live = i < total && gy >= 0 && gy < H;
+                const int i = tid + (k0 + u) * 256;
+                int t, xc, ch;
+                item(i, t, xc, ch);
+                const int gy = y0 - 1 + t;
+                const bool live = k0 + u < NP && i < total && gy >= 0 && gy < H;
                 const __bf16 *src = 8 * ch < Cu ? ub + (size_t)((gy >> 1) * Wh + (xc >> 1)) * Cu + 8 * ch
                                                 : sb + (size_t)(gy * W + xc) * Cs + (8 * ch - Cu);
                 raw[u] = live ? *(const bf16x8 *)src : zero;
-                dst[u] = i < total ? (t * (W + 2) + xc + 1) * SA + ch * 16 : -1;
-                ch8[u] = live ? 8 * ch : -1;
             }
+            if (!synced) { __syncthreads(); synced = true; }   // the (a, b) table
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (dst[u] < 0) continue;
+                const int i = tid + (k0 + u) * 256;
+                if (k0 + u >= NP || i >= total) break;
+                int t, xc, ch;
+                item(i, t, xc, ch);
+                const int gy = y0 - 1 + t;
                 bf16x8 o = zero;
-                if (ch8[u] >= 0) {
-                    const float *abp = abt + 2 * ch8[u];
+                if (gy >= 0 && gy < H) {
+                    const float *abp = abt + 16 * ch;
 #pragma unroll
                     for (int j = 0; j < 8; j += 2) {
-                        const f32x4 k = *(const f32x4 *)(abp + 2 * j);   // a, b of channels j and j + 1
-                        const float z0 = __builtin_fmaf((float)raw[u][j], k[0], k[1]), z1 = __builtin_fmaf((float)raw[u][j + 1], k[2], k[3]);
+                        const f32x4 kk = *(const f32x4 *)(abp + 2 * j);   // a, b of channels j and j + 1
+                        const float z0 = __builtin_fmaf((float)raw[u][j], kk[0], kk[1]),
+                                    z1 = __builtin_fmaf((float)raw[u][j + 1], kk[2], kk[3]);
                         o[j] = (__bf16)(z0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z0 * -1.4426950408889634f)));
                         o[j + 1] = (__bf16)(z1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z1 * -1.4426950408889634f)));
                     }
                 }
-                *(bf16x8 *)(tile + dst[u]) = o;
+                *(bf16x8 *)(tile + (t * (W + 2) + xc + 1) * SA + ch * 16) = o;
             }
         }
         clear_halo<CA, 256>(tile, W, rows + 2, 0, 0, tid);
@@ -125,7 +139,7 @@ bool launch_tile_as(const ConvArgs &a, hipStream_t s)
     // the tallest band whose tile fits NP x 256 staged items and 76 KB of LDS (two workgroups per CU)
     int nb = 1, R = a.H;
     auto fits = [&](int r) {
-        return (GNUP || (int64_t)(r + 2) * a.W * (CA / 8) <= (int64_t)NP * 256) &&
+        return (int64_t)(r + 2) * a.W * (CA / 8) <= (int64_t)NP * 256 &&
                (r + 2) * (a.W + 2) * SA + 2 * COUT * 4 + (GNUP ? 2 * CA * 4 : 0) + 16 <= 76 * 1024;
     };
     while (!fits(R)) {

@@ -26,6 +26,10 @@ constexpr int kCin[NBLK] = {32, 32, 64, 192, 96};
 constexpr int kWidth[NBLK] = {32, 64, 128, 64, 32};
 constexpr int EMB = 32, TEMB = 128, TVEC = 320;
 
+typedef _Float16 act16;
+typedef __attribute__((ext_vector_type(4))) _Float16 a16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 a16x8;
+
 DEVI float rsqrt_canon(float v)
 {
     float r = __uint_as_float(0x5f3759dfu - (__float_as_uint(v) >> 1));
@@ -39,16 +43,24 @@ DEVI float rsqrt_canon(float v)
     return r;
 }
 
-// Activations between the kernels are float32 (parity mode; bf16 mode on shapes its fused kernels do not cover) or bf16
-// (bf16 mode otherwise: every tensor is rounded once where it is produced, all arithmetic stays float32).
+// Activations between the kernels are float32 (parity mode; bf16 mode on shapes its fused kernels do not cover) or IEEE half
+// (bf16 mode otherwise: every tensor is rounded once where it is produced, all arithmetic stays float32).  Half, not bf16:
+// these tensors are rounded to bf16 again as convolution operands, and a bf16 store in between would double that rounding
+// noise (measured: 1.4 x the error against the float32 oracle); half's 11 bits add 1/64 of it.  Stores saturate at +-65504.
 DEVI f32x4 ld4(const float *p) { return *(const f32x4 *)p; }
-DEVI f32x4 ld4(const __bf16 *p)
+DEVI f32x4 ld4(const act16 *p)
 {
-    const bf16x4 v = *(const bf16x4 *)p;
+    const a16x4 v = *(const a16x4 *)p;
     return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
 DEVI void st4(float *p, f32x4 v) { *(f32x4 *)p = v; }
-DEVI void st4(__bf16 *p, f32x4 v) { *(bf16x4 *)p = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; }
+DEVI void st4(act16 *p, f32x4 v)
+{
+    a16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (act16)__builtin_amdgcn_fmed3f(v[j], -65504.0f, 65504.0f);
+    *(a16x4 *)p = o;
+}
 
 struct TimeW {
     const float *d1_w, *d1_b, *d2_w, *d2_b;
@@ -211,10 +223,10 @@ __global__ __launch_bounds__(THREADS, gn_blocks_per_cu(THREADS, NV, sizeof(AT) =
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Q = C >> 2, Qg = Q >> 3, nq = HW * Q;          // quads per pixel, per group and pixel, per sample
     const int c4 = tid % Q, grp = c4 / Qg;
-    // bf16 input stays packed in the registers (half as many as float32 values: twice the workgroups per CU, which is what
-    // hides one sample's load -> reduce -> reduce -> store chain behind another's) and is widened at each of its three uses
+    // 16-bit input stays packed in the registers (half as many as float32 values: twice the workgroups per CU, which is what
+    // hides one sample's load -> reduce -> reduce -> store chain behind another's) and is widened at each of its uses
     constexpr bool PACKED = sizeof(AT) == 2;
-    using VT = typename std::conditional<PACKED, bf16x4, f32x4>::type;
+    using VT = typename std::conditional<PACKED, a16x4, f32x4>::type;
     auto raw = [](const AT *p) { return *(const VT *)p; };
     // (the packed value passes through an empty asm at each use, or the compiler widens once and keeps the float32 copy)
     auto wide = [](const VT &p) {
@@ -222,8 +234,8 @@ __global__ __launch_bounds__(THREADS, gn_blocks_per_cu(THREADS, NV, sizeof(AT) =
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
             u32x2 u = __builtin_bit_cast(u32x2, p);
             asm volatile("" : "+v"(u));
-            return f32x4{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16),
-                         __uint_as_float(u[1] & 0xffff0000u)};
+            const a16x4 h = __builtin_bit_cast(a16x4, u);
+            return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
         } else {
             return p;
         }
@@ -334,12 +346,9 @@ bool gn_fused_try(const void *x, bool a16, const UpCatSrc &uc, int64_t B, int HW
     const int Q = C / 4;
     if (THREADS % Q != 0 || (int64_t)HW * Q > (int64_t)THREADS * NV) return false;
     if (probe) return true;
-    if (a16 && ab)
-        hipLaunchKernelGGL((bf_gn_fused_bf16_kernel<THREADS, NV, __bf16, true>), dim3((unsigned)B), dim3(THREADS), 0, s, (const __bf16 *)x,
+    if (a16)
+        hipLaunchKernelGGL((bf_gn_fused_bf16_kernel<THREADS, NV, act16, true>), dim3((unsigned)B), dim3(THREADS), 0, s, (const act16 *)x,
                            uc, HW, C, gamma, beta, y, ab);
-    else if (a16)
-        hipLaunchKernelGGL((bf_gn_fused_bf16_kernel<THREADS, NV, __bf16>), dim3((unsigned)B), dim3(THREADS), 0, s, (const __bf16 *)x, uc, HW,
-                           C, gamma, beta, y, ab);
     else
         hipLaunchKernelGGL((bf_gn_fused_bf16_kernel<THREADS, NV, float>), dim3((unsigned)B), dim3(THREADS), 0, s, (const float *)x, uc, HW, C,
                            gamma, beta, y, ab);
@@ -347,7 +356,7 @@ bool gn_fused_try(const void *x, bool a16, const UpCatSrc &uc, int64_t B, int HW
 }
 
 // probe: only tell whether an instance covers the sample
-// a16: x (or uc's two tensors) holds bf16; ab (a16 only): statistics only, the (a, b) pairs go there and y is not written
+// a16: x (or uc's two tensors) holds half and only the statistics are taken: the (a, b) pairs go to ab, y is not written
 bool gn_fused_bf16(const void *x, bool a16, const UpCatSrc &uc, int64_t B, int HW, int C, const float *gamma, const float *beta,
                    __bf16 *y, hipStream_t s, bool probe = false, float *ab = nullptr)
 {
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(256) void bf_shortcut_kernel(const float *__restric
 // bf16 convolution mode: the projected shortcut out = (conv1x1(x) + bias) + h on the bf16 matrix cores.  One wavefront =
 // 32 pixels x all output channels; x is read as float32 (eight consecutive channels per lane and step) and rounded to bf16
 // on the way into the MFMA; wpack: bf16 A fragments [c / 16][Cout / 32][lane][8] (the centre tap of the 3x3 packing).
-// HBM-bound: x, h in and out out once each.  AT = __bf16: x is the operand as it lies in memory, h and out are bf16 too.
+// HBM-bound: x, h in and out out once each.  AT = act16: x, h and out hold half.
 template <int MT, typename AT>
 __global__ __launch_bounds__(256) void bf_shortcut_mfma_kernel(const AT *__restrict__ x, UpCatSrc uc, int Cin,
                                                                const bf16x8 *__restrict__ wpack, const float *__restrict__ bias,
@@ -416,7 +425,9 @@ __global__ __launch_bounds__(256) void bf_shortcut_mfma_kernel(const AT *__restr
             bv = bf16x8{(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3],
                         (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
         } else {
-            bv = *(const bf16x8 *)src;
+            const a16x8 v = *(const a16x8 *)src;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bv[j] = (__bf16)(float)v[j];
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -488,8 +499,8 @@ __global__ __launch_bounds__(256) void bf_head_kernel(const AT *__restrict__ r, 
     proba[i] = __fdiv_rn(1.0f, __fadd_rn(1.0f, cexp(-acc)));
 }
 
-// bf16 activations handed out as float32 (the optional ResBlock outputs of a forward call)
-__global__ __launch_bounds__(256) void bf_widen_kernel(const __bf16 *__restrict__ in, float *__restrict__ out, int64_t n)
+// half activations handed out as float32 (the optional ResBlock outputs of a forward call)
+__global__ __launch_bounds__(256) void bf_widen_kernel(const act16 *__restrict__ in, float *__restrict__ out, int64_t n)
 {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i < n) st4(out + i, ld4(in + i));
@@ -622,11 +633,11 @@ int time_vectors(idm_bitflip *m, const float *emb_host, int rows, hipStream_t s)
     return IDM_OK;
 }
 
-// y: float32, or bf16 in the same buffer when `half`; a16 (bf16 mode only): x holds bf16
+// y: float32, or bf16 in the same buffer when `half`
 void gn_silu(const float *x, int64_t B, int HW, int C, const float *gamma, const float *beta, float *ab, float *y, bool half,
-             hipStream_t s, const UpCatSrc &uc = UpCatSrc{}, bool a16 = false)
+             hipStream_t s, const UpCatSrc &uc = UpCatSrc{})
 {
-    if (half && gn_fused_bf16(x, a16, uc, B, HW, C, gamma, beta, (__bf16 *)y, s)) return;
+    if (half && gn_fused_bf16(x, false, uc, B, HW, C, gamma, beta, (__bf16 *)y, s)) return;
     hipLaunchKernelGGL(bf_gn_stats_kernel, dim3((unsigned)((B * 8 + 3) / 4)), dim3(256), 0, s, x, B, HW, C, gamma, beta, ab);
     const int64_t n = B * HW * C;
     if (half)
@@ -639,14 +650,13 @@ void gn_silu(const float *x, int64_t B, int HW, int C, const float *gamma, const
 // resid / res_out (bf16 mode only, may be null): when the LDS-tiled kernel covers the shape it writes
 // res_out = (conv + bias) + resid instead of out and the function returns true (the block's identity shortcut rides in the
 // convolution's epilogue); false: out holds the plain convolution.
-// a16 (bf16 mode on shapes the LDS-tiled kernel covers): out, resid and res_out hold bf16.
 bool conv3(const float *in, int64_t B, int H, int W, int Cin, const void *wpack, const float *bias, const float *tadd,
-           float *out, int Cout, bool half, hipStream_t s, const float *resid = nullptr, float *res_out = nullptr, bool a16 = false)
+           float *out, int Cout, bool half, hipStream_t s, const float *resid = nullptr, float *res_out = nullptr)
 {
     ConvArgs a = {};
     a.in0 = in; a.in1 = nullptr; a.C0 = Cin; a.C1 = 0; a.H = H; a.W = W; a.B = B; a.wpack = wpack; a.bias = bias;
     a.scale = nullptr; a.shift = nullptr; a.tadd = tadd; a.out = out; a.Cout = Cout; a.mode = CONV_PLAIN; a.silu = 0;
-    a.out_f32 = 1; a.io_bf16 = a16;
+    a.out_f32 = 1;
     if (!half) { launch_conv_f32(a, s); return false; }
     if (resid && res_out) {
         a.resid = resid; a.out = res_out;
@@ -672,7 +682,7 @@ void shortcut_mfma(int mt, const void *x, const UpCatSrc &uc, int Cin, const bf1
 #undef IDM_SC
 }
 
-// The ResBlock on bf16 activations with both GroupNorms folded into the convolutions: a statistics kernel leaves the (a, b)
+// The ResBlock on half activations with both GroupNorms folded into the convolutions: a statistics kernel leaves the (a, b)
 // pairs of every (sample, channel), the convolution applies y = swish(x a + b) while it stages its tiles, so the normalised
 // tensors never go through memory.  uc.up == nullptr: the input is the plain tensor x.  false (an instance is missing):
 // nothing useful was written, the caller runs the unfolded kernels.
@@ -684,7 +694,7 @@ bool resblock_act16(idm_bitflip *m, int i, const float *x, const UpCatSrc &uc, i
                       const float *resid, float *dst) {
         ConvArgs a = {};
         a.in0 = up; a.in1 = full; a.C0 = Cu; a.C1 = Cf; a.H = H; a.W = W; a.B = B; a.wpack = wpack; a.bias = bias; a.tadd = tadd;
-        a.out = dst; a.Cout = Cw; a.mode = CONV_UPCAT; a.out_f32 = 1; a.io_bf16 = 1; a.gn_ab = ab; a.resid = resid;
+        a.out = dst; a.Cout = Cw; a.mode = CONV_UPCAT; a.out_f32 = 1; a.io_f16 = 1; a.gn_ab = ab; a.resid = resid;
         return launch_conv_tile_bf16(a, s);
     };
     if (!gn_fused_bf16(x, true, uc, B, HW, Cin, m->t[tb(i, K_G1_G)], m->t[tb(i, K_G1_B)], nullptr, s, false, ab)) return false;
@@ -697,7 +707,7 @@ bool resblock_act16(idm_bitflip *m, int i, const float *x, const UpCatSrc &uc, i
     // goes through `out` and the shortcut kernel adds in place there instead
     if (identity) return folded(nullptr, 0, tbuf, Cw, m->c2_pack16[i], m->t[tb(i, K_C2_B)], nullptr, x, out);
     if (!folded(nullptr, 0, tbuf, Cw, m->c2_pack16[i], m->t[tb(i, K_C2_B)], nullptr, nullptr, out)) return false;
-    shortcut_mfma<__bf16>(Cw / 32, x, uc, Cin, (const bf16x8 *)m->s_pack16[i], m->t[tb(i, K_S_B)], out, out, B * HW, s);
+    shortcut_mfma<act16>(Cw / 32, x, uc, Cin, (const bf16x8 *)m->s_pack16[i], m->t[tb(i, K_S_B)], out, out, B * HW, s);
     return true;
 }
 
@@ -705,9 +715,8 @@ bool resblock_act16(idm_bitflip *m, int i, const float *x, const UpCatSrc &uc, i
 // cat (optional): x = Concatenate([UpSampling2D(cat->up), cat->skip]).  In the bf16 mode the block's two readers of x (the
 // first GroupNorm and the projected shortcut) read the two tensors in place when their fused kernels cover the shape;
 // otherwise the concatenation is first written to x.
-// a16 (only where act16_covers() holds: every fused kernel covers the shape): x, tbuf and out hold bf16.
 void resblock(idm_bitflip *m, int i, float *x, int64_t B, int H, int W, const float *tvec, float *out, float *ta,
-              float *tbuf, float *ab, hipStream_t s, const UpCatSrc *cat = nullptr, bool a16 = false)
+              float *tbuf, float *ab, hipStream_t s, const UpCatSrc *cat = nullptr)
 {
     const int Cin = kCin[i], Cw = kWidth[i], HW = H * W;
     const bool half = m->precision == IDM_BF16;
@@ -715,27 +724,25 @@ void resblock(idm_bitflip *m, int i, float *x, int64_t B, int H, int W, const fl
     UpCatSrc uc = {};
     if (cat) {
         const bool in_place = mfma_shortcut && cat->Cu % 16 == 0 && cat->Cs % 4 == 0 &&
-                              gn_fused_bf16(nullptr, a16, *cat, B, HW, Cin, nullptr, nullptr, nullptr, s, true);
+                              gn_fused_bf16(nullptr, false, *cat, B, HW, Cin, nullptr, nullptr, nullptr, s, true);
         if (in_place) uc = *cat;
         else
             hipLaunchKernelGGL(bf_upcat_kernel, dim3(blocks(B * HW * Cin / 4)), dim3(256), 0, s, (const float *)cat->up,
                                (const float *)cat->skip, x, B, cat->Hh, cat->Wh, cat->Cu, cat->Cs);
     }
-    if (a16 && resblock_act16(m, i, x, uc, B, H, W, tvec, out, tbuf, ab, s)) return;
-    gn_silu(x, B, HW, Cin, m->t[tb(i, K_G1_G)], m->t[tb(i, K_G1_B)], ab, ta, half, s, uc, a16);
-    conv3(ta, B, H, W, Cin, half ? m->c1_pack16[i] : m->c1_pack[i], m->t[tb(i, K_C1_B)], tvec, tbuf, Cw, half, s, nullptr, nullptr, a16);
-    gn_silu(tbuf, B, HW, Cw, m->t[tb(i, K_G2_G)], m->t[tb(i, K_G2_B)], ab, ta, half, s, UpCatSrc{}, a16);
+    gn_silu(x, B, HW, Cin, m->t[tb(i, K_G1_G)], m->t[tb(i, K_G1_B)], ab, ta, half, s, uc);
+    conv3(ta, B, H, W, Cin, half ? m->c1_pack16[i] : m->c1_pack[i], m->t[tb(i, K_C1_B)], tvec, tbuf, Cw, half, s);
+    gn_silu(tbuf, B, HW, Cw, m->t[tb(i, K_G2_G)], m->t[tb(i, K_G2_B)], ab, ta, half, s);
     // identity shortcut (Cin == width, :188-192 take the other branch): out = x + h, in the bf16 mode inside the convolution
     const bool identity = !m->s_pack[i] && !(half && m->s_pack16[i]);
     if (conv3(ta, B, H, W, Cw, half ? m->c2_pack16[i] : m->c2_pack[i], m->t[tb(i, K_C2_B)], nullptr, tbuf, Cw, half, s,
-              half && identity ? x : nullptr, out, a16))
+              half && identity ? x : nullptr, out))
         return;
     const int64_t npix = B * HW;
     if (mfma_shortcut) {
         const bf16x8 *wp = (const bf16x8 *)m->s_pack16[i];
         const float *sb = m->t[tb(i, K_S_B)];
-        if (a16) shortcut_mfma<__bf16>(Cw / 32, x, uc, Cin, wp, sb, tbuf, out, npix, s);
-        else shortcut_mfma<float>(Cw / 32, x, uc, Cin, wp, sb, tbuf, out, npix, s);
+        shortcut_mfma<float>(Cw / 32, x, uc, Cin, wp, sb, tbuf, out, npix, s);
     } else if (m->s_pack[i]) {
         // projected shortcut (:188-192) on the matrix cores: the centre tap alone is a 1x1 convolution with the
         // same k-ordered chain; out = (chain + bias) + h
@@ -750,10 +757,10 @@ void resblock(idm_bitflip *m, int i, float *x, int64_t B, int H, int W, const fl
     }
 }
 
-// bf16 mode: may the activations between the kernels be bf16?  Only where no fallback kernel (two-pass GroupNorm, written-out
-// concatenation, per-layer convolution, scalar shortcut: all float32 in, float32 out) would run: maps at most 32 wide for the
-// LDS-tiled convolution at all three levels, a one-workgroup GroupNorm instance for every (pixels, channels) pair, and the
-// MFMA kernel for every projected shortcut.  ISINGDIFF_BITFLIP_ACT=f32 keeps float32 activations (comparison runs).
+// bf16 mode: may the activations between the kernels be half, with the GroupNorms folded into the convolutions
+// (resblock_act16)?  Where those kernels cover every level: maps at most 32 wide for the LDS-tiled convolution, a one-workgroup
+// GroupNorm instance for every (pixels, channels) pair, the MFMA kernel for every projected shortcut.  Elsewhere the mode
+// runs on float32 activations (resblock).  ISINGDIFF_BITFLIP_ACT=f32 selects those everywhere (comparison runs).
 bool act16_covers(const idm_bitflip *m, int64_t B, int H, int W)
 {
     static const bool off = [] { const char *e = getenv("ISINGDIFF_BITFLIP_ACT"); return e && !strcmp(e, "f32"); }();
@@ -763,6 +770,7 @@ bool act16_covers(const idm_bitflip *m, int64_t B, int H, int W)
         if (!gn_fused_bf16(nullptr, true, UpCatSrc{}, B, HW, kCin[i], nullptr, nullptr, nullptr, nullptr, true) ||
             !gn_fused_bf16(nullptr, true, UpCatSrc{}, B, HW, kWidth[i], nullptr, nullptr, nullptr, nullptr, true))
             return false;
+        if (!m->c1_pack16[i] || !m->c2_pack16[i]) return false;
         if (kCin[i] != kWidth[i] && !(m->s_pack16[i] && kWidth[i] % 32 == 0 && kWidth[i] <= 128 && kCin[i] % 16 == 0)) return false;
     }
     return true;
@@ -775,7 +783,7 @@ int forward_chunk(idm_bitflip *m, const uint8_t *x, const float *tvec, float *pr
     const size_t hw = (size_t)H * W;
     const bool a16 = act16_covers(m, Bc, H, W);
     float *p = (float *)m->ws;
-    // (with bf16 activations every buffer but ta uses half of its float32 size)
+    // (with half activations the buffers use half of their float32 size; cat and ta stay unused)
     auto take = [&](size_t per) { float *q = p; p += per * Bc; return q; };
     float *x0 = take(hw * 32), *r0 = take(hw * 32), *r1 = take(hw * 16), *r2 = take(hw * 8), *cat = take(hw * 96),
           *ta = take(hw * 96), *tbuf = take(hw * 32), *pl = take(hw * 8), *d3 = take(hw * 16), *d4 = take(hw * 32);
@@ -784,31 +792,41 @@ int forward_chunk(idm_bitflip *m, const uint8_t *x, const float *tvec, float *pr
     const float *tv[NBLK];
     int o = 0;
     for (int i = 0; i < NBLK; ++i) { tv[i] = tvec + o; o += kWidth[i]; }
-    if (a16)
-        hipLaunchKernelGGL(bf_in_kernel<__bf16>, dim3(blocks(Bc * hw * 8)), dim3(256), 0, s, x, m->t[T_IN_W], m->t[T_IN_B], (__bf16 *)x0,
+    const UpCatSrc cat3 = {r2, r1, H4, W4, 128, 64}, cat4 = {d3, r0, H2, W2, 64, 32}, plain = {};
+    if (a16) {
+        auto maxpool = [&](const float *in, float *out, int h, int w, int C) {
+            hipLaunchKernelGGL(bf_maxpool_kernel<act16>, dim3(blocks(Bc * (int64_t)(h / 2) * (w / 2) * C / 4)), dim3(256), 0, s,
+                               (const act16 *)in, (act16 *)out, Bc, h, w, C);
+        };
+        hipLaunchKernelGGL(bf_in_kernel<act16>, dim3(blocks(Bc * hw * 8)), dim3(256), 0, s, x, m->t[T_IN_W], m->t[T_IN_B], (act16 *)x0,
                            (int64_t)(Bc * hw));
-    else
+        bool ok = resblock_act16(m, 0, x0, plain, Bc, H, W, tv[0], r0, tbuf, ab, s);
+        maxpool(r0, pl, H, W, 32);
+        ok = ok && resblock_act16(m, 1, pl, plain, Bc, H2, W2, tv[1], r1, tbuf, ab, s);
+        maxpool(r1, pl, H2, W2, 64);
+        ok = ok && resblock_act16(m, 2, pl, plain, Bc, H4, W4, tv[2], r2, tbuf, ab, s);
+        ok = ok && resblock_act16(m, 3, nullptr, cat3, Bc, H2, W2, tv[3], d3, tbuf, ab, s);
+        ok = ok && resblock_act16(m, 4, nullptr, cat4, Bc, H, W, tv[4], d4, tbuf, ab, s);
+        if (!ok) return idm_set_error(IDM_ERR_INVALID, "bit-flip model: a kernel of the half-activation path does not cover this shape");
+        hipLaunchKernelGGL(bf_head_kernel<act16>, dim3(blocks(Bc * hw)), dim3(256), 0, s, (const act16 *)d4, m->t[T_OUT_W], m->t[T_OUT_B],
+                           proba, (int64_t)(Bc * hw));
+    } else {
+        auto maxpool = [&](const float *in, float *out, int h, int w, int C) {
+            hipLaunchKernelGGL(bf_maxpool_kernel<float>, dim3(blocks(Bc * (int64_t)(h / 2) * (w / 2) * C / 4)), dim3(256), 0, s, in, out,
+                               Bc, h, w, C);
+        };
         hipLaunchKernelGGL(bf_in_kernel<float>, dim3(blocks(Bc * hw * 8)), dim3(256), 0, s, x, m->t[T_IN_W], m->t[T_IN_B], x0,
                            (int64_t)(Bc * hw));
-    auto maxpool = [&](const float *in, float *out, int h, int w, int C) {
-        const unsigned grid = blocks(Bc * (int64_t)(h / 2) * (w / 2) * C / 4);
-        if (a16) hipLaunchKernelGGL(bf_maxpool_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16 *)in, (__bf16 *)out, Bc, h, w, C);
-        else hipLaunchKernelGGL(bf_maxpool_kernel<float>, dim3(grid), dim3(256), 0, s, in, out, Bc, h, w, C);
-    };
-    resblock(m, 0, x0, Bc, H, W, tv[0], r0, ta, tbuf, ab, s, nullptr, a16);
-    maxpool(r0, pl, H, W, 32);
-    resblock(m, 1, pl, Bc, H2, W2, tv[1], r1, ta, tbuf, ab, s, nullptr, a16);
-    maxpool(r1, pl, H2, W2, 64);
-    resblock(m, 2, pl, Bc, H4, W4, tv[2], r2, ta, tbuf, ab, s, nullptr, a16);
-    const UpCatSrc cat3 = {r2, r1, H4, W4, 128, 64}, cat4 = {d3, r0, H2, W2, 64, 32};
-    resblock(m, 3, cat, Bc, H2, W2, tv[3], d3, ta, tbuf, ab, s, &cat3, a16);
-    resblock(m, 4, cat, Bc, H, W, tv[4], d4, ta, tbuf, ab, s, &cat4, a16);
-    if (a16)
-        hipLaunchKernelGGL(bf_head_kernel<__bf16>, dim3(blocks(Bc * hw)), dim3(256), 0, s, (const __bf16 *)d4, m->t[T_OUT_W], m->t[T_OUT_B],
-                           proba, (int64_t)(Bc * hw));
-    else
+        resblock(m, 0, x0, Bc, H, W, tv[0], r0, ta, tbuf, ab, s);
+        maxpool(r0, pl, H, W, 32);
+        resblock(m, 1, pl, Bc, H2, W2, tv[1], r1, ta, tbuf, ab, s);
+        maxpool(r1, pl, H2, W2, 64);
+        resblock(m, 2, pl, Bc, H4, W4, tv[2], r2, ta, tbuf, ab, s);
+        resblock(m, 3, cat, Bc, H2, W2, tv[3], d3, ta, tbuf, ab, s, &cat3);
+        resblock(m, 4, cat, Bc, H, W, tv[4], d4, ta, tbuf, ab, s, &cat4);
         hipLaunchKernelGGL(bf_head_kernel<float>, dim3(blocks(Bc * hw)), dim3(256), 0, s, (const float *)d4, m->t[T_OUT_W], m->t[T_OUT_B],
                            proba, (int64_t)(Bc * hw));
+    }
     if (taps) {
         const float *src[NBLK] = {r0, r1, r2, d3, d4};
         const size_t per[NBLK] = {hw * 32, hw * 16, hw * 8, hw * 16, hw * 32};
@@ -816,7 +834,7 @@ int forward_chunk(idm_bitflip *m, const uint8_t *x, const float *tvec, float *pr
             if (!taps[i]) continue;
             float *dst = taps[i] + (size_t)tap_off * per[i];
             if (a16)
-                hipLaunchKernelGGL(bf_widen_kernel, dim3(blocks((int64_t)(per[i] * Bc / 4))), dim3(256), 0, s, (const __bf16 *)src[i], dst,
+                hipLaunchKernelGGL(bf_widen_kernel, dim3(blocks((int64_t)(per[i] * Bc / 4))), dim3(256), 0, s, (const act16 *)src[i], dst,
                                    (int64_t)(per[i] * Bc));
             else
                 BFCHK(hipMemcpyAsync(dst, src[i], per[i] * Bc * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -835,11 +853,14 @@ int check_hw(int64_t B, int H, int W)
 
 int64_t pick_chunk(int64_t B, int H, int W, int64_t want)
 {
+    // at most 8 GiB of workspace; without a caller's choice the chunks are equal (a short last chunk runs its kernels on a
+    // fraction of the chip)
     const size_t per = (ws_floats(H, W) + (size_t)H * W) * sizeof(float);
-    int64_t cap = (int64_t)((size_t)4 << 30) / (int64_t)per;
+    int64_t cap = (int64_t)((size_t)8 << 30) / (int64_t)per;
     if (cap < 1) cap = 1;
-    int64_t c = want > 0 ? want : cap;
-    return std::min<int64_t>(std::min<int64_t>(c, cap), B);
+    if (want > 0) return std::min<int64_t>(std::min<int64_t>(want, cap), B);
+    const int64_t n = (B + cap - 1) / cap;
+    return (B + n - 1) / n;
 }
 
 }  // namespace

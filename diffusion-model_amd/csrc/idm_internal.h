@@ -50,10 +50,11 @@ struct ConvArgs {
     // (tap_lo = 4, tap_hi = 5 with a one-tap pack is a 1x1 convolution); resid (same shape as out) is added last
     int tap_lo = 0, tap_hi = 9;
     const float *resid = nullptr;
-    // LDS-tiled float32-output kernel only: out and resid hold bf16 (the raw convolution, rounded once)
-    int io_bf16 = 0;
-    // ... with CONV_UPCAT and io_bf16: in0 / in1 hold the raw bf16 tensors and y = swish(x a + b), (a, b) pairs per (sample,
-    // channel) as (B, C0 + C1, 2) floats, is applied while the tile is staged (GroupNorm folded into the convolution)
+    // LDS-tiled kernel with CONV_UPCAT only (io_f16 and gn_ab go together): in0 / in1, out and resid hold IEEE half; the input
+    // is the raw tensor and y = swish(x a + b), (a, b) pairs per (sample, channel) as (B, C0 + C1, 2) floats, is applied
+    // while the tile is staged (GroupNorm folded into the convolution); the raw convolution leaves rounded once to half,
+    // saturated at +-65504.  C0 = 0: a plain tensor in in1.
+    int io_f16 = 0;
     const float *gn_ab = nullptr;
 };
 

@@ -4,20 +4,24 @@
 // sum; mnist_diffusion/mnist_diffusion.py:168-193), on the sliding-window MFMA stage the Ising kernels use: a workgroup
 // stages R + 2 rows of one sample in LDS ([row][col][channel], zero halo), its four wavefronts split the R output rows
 // (or, for maps narrower than 32, the 32-pixel groups of several rows) and each MFMA tile's accumulators leave as
-// float32, 16 bytes per lane and channel quad - or, with ConvArgs::io_bf16, rounded once to bf16 (and the residual read as
-// bf16): the sampler keeps its activations in bf16 between kernels then.  One workgroup per (sample, band); weights come
-// from L2 through the stage's register ring.
-// GNUP instances take the ResBlock's input as it is before its first GroupNorm, x = Concatenate([UpSampling2D(up), skip])
-// (:225-226, :230-231) in bf16, and apply y = swish(x a + b) with the (a, b) pairs of the sample's channels (ConvArgs::gn_ab)
-// while they stage the tile: the normalised tensor never goes through memory.
+// float32, 16 bytes per lane and channel quad.  One workgroup per (sample, band); weights come from L2 through the stage's
+// register ring.
+// GNUP instances (ConvArgs::io_f16 + gn_ab) work on IEEE-half activations: they take a ResBlock convolution's input as it
+// is BEFORE the GroupNorm in front of it - a plain tensor or x = Concatenate([UpSampling2D(up), skip]) (:225-226, :230-231) -
+// and apply y = swish(x a + b) with the (a, b) pairs of the sample's channels while they stage the tile, so the normalised
+// tensor never goes through memory; output and residual are half too (stores saturate at +-65504).
 #include "idm_conv_stage.h"
 
 #include <algorithm>
 
 namespace {
 
+typedef _Float16 act16;
+typedef __attribute__((ext_vector_type(4))) _Float16 a16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 a16x8;
+
 struct GnUpSrc {
-    const __bf16 *skip;   // (B, H, W, CA - Cu); the kernel's `in` is up, (B, H / 2, W / 2, Cu)
+    const act16 *skip;    // (B, H, W, CA - Cu); the kernel's `in` is up, (B, H / 2, W / 2, Cu)
     const float *ab;      // (B, CA, 2)
     int Cu;
 };
@@ -43,10 +47,11 @@ __global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__r
     if constexpr (GNUP) {
         constexpr int CH = CA / 8;
         const int Cu = gu.Cu, Cs = CA - Cu, Hh = H >> 1, Wh = W >> 1, ipr = W * CH, total = (rows + 2) * ipr;
-        const __bf16 *ub = in + (size_t)b * Hh * Wh * Cu, *sb = gu.skip + (size_t)b * H * W * Cs;
+        const act16 *ub = (const act16 *)in + (size_t)b * Hh * Wh * Cu, *sb = gu.skip + (size_t)b * H * W * Cs;
         bf16x8 zero;
+        a16x8 zraw;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) zero[j] = (__bf16)0.0f;
+        for (int j = 0; j < 8; ++j) { zero[j] = (__bf16)0.0f; zraw[j] = (act16)0.0f; }
         // items (tile row, column, eight channels), in rounds of U per thread: a round's loads are all in flight before its
         // first item is used (all NP at once would cost the 24-item instances their second workgroup per CU)
         constexpr int U = 8;
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__r
         bool synced = false;
 #pragma unroll
         for (int k0 = 0; k0 < NP; k0 += U) {
-            bf16x8 raw[U];
+            a16x8 raw[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = tid + (k0 + u) * 256;
@@ -69,9 +74,9 @@ __global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__r
                 item(i, t, xc, ch);
                 const int gy = y0 - 1 + t;
                 const bool live = k0 + u < NP && i < total && gy >= 0 && gy < H;
-                const __bf16 *src = 8 * ch < Cu ? ub + (size_t)((gy >> 1) * Wh + (xc >> 1)) * Cu + 8 * ch
-                                                : sb + (size_t)(gy * W + xc) * Cs + (8 * ch - Cu);
-                raw[u] = live ? *(const bf16x8 *)src : zero;
+                const act16 *src = 8 * ch < Cu ? ub + (size_t)((gy >> 1) * Wh + (xc >> 1)) * Cu + 8 * ch
+                                               : sb + (size_t)(gy * W + xc) * Cs + (8 * ch - Cu);
+                raw[u] = live ? *(const a16x8 *)src : zraw;
             }
             if (!synced) { __syncthreads(); synced = true; }   // the (a, b) table
 #pragma unroll
@@ -122,10 +127,13 @@ __global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__r
                 *(f32x4 *)(ob + o + 8 * g) = z;
             } else {
                 if (rb) {
-                    const bf16x4 r4 = *(const bf16x4 *)(rb + o + 8 * g);
+                    const a16x4 r4 = *(const a16x4 *)(rb + o + 8 * g);
                     z = z + f32x4{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
                 }
-                *(bf16x4 *)(ob + o + 8 * g) = pack4(z[0], z[1], z[2], z[3]);
+                a16x4 o4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o4[j] = (act16)__builtin_amdgcn_fmed3f(z[j], -65504.0f, 65504.0f);
+                *(a16x4 *)(ob + o + 8 * g) = o4;
             }
         }
     });
@@ -138,9 +146,12 @@ bool launch_tile_as(const ConvArgs &a, hipStream_t s)
     constexpr int SA = CA * 2 + 16;
     // the tallest band whose tile fits NP x 256 staged items and 76 KB of LDS (two workgroups per CU)
     int nb = 1, R = a.H;
+    // (76 KB: two workgroups per CU; shorter bands for three or four - the one-slice instances have the registers for it -
+    // measured no faster: 52 KB +0.3 %, 39 KB -2.6 %, 30 KB -13 % for the bit-flip sampler)
+    constexpr int budget = 76 * 1024;
     auto fits = [&](int r) {
         return (int64_t)(r + 2) * a.W * (CA / 8) <= (int64_t)NP * 256 &&
-               (r + 2) * (a.W + 2) * SA + 2 * COUT * 4 + (GNUP ? 2 * CA * 4 : 0) + 16 <= 76 * 1024;
+               (r + 2) * (a.W + 2) * SA + 2 * COUT * 4 + (GNUP ? 2 * CA * 4 : 0) + 16 <= budget;
     };
     while (!fits(R)) {
         if (R == 1) return false;
@@ -160,14 +171,14 @@ bool launch_tile_as(const ConvArgs &a, hipStream_t s)
     }
     hipLaunchKernelGGL(kernel, dim3((unsigned)(a.B * nb)), dim3(256), lds, s, (const __bf16 *)a.in0, (const bf16x8 *)a.wpack, a.bias,
                        a.tadd, (const OT *)a.resid, (OT *)a.out, a.H, a.W, R, nb,
-                       GnUpSrc{(const __bf16 *)a.in1, a.gn_ab, a.C0});
+                       GnUpSrc{(const act16 *)a.in1, a.gn_ab, a.C0});
     return true;
 }
 
 template <int CA, int COUT, int NT, int MS, int WD, int NP>
 bool launch_tile(const ConvArgs &a, hipStream_t s)
 {
-    return a.io_bf16 ? launch_tile_as<CA, COUT, NT, MS, WD, NP, __bf16>(a, s) : launch_tile_as<CA, COUT, NT, MS, WD, NP, float>(a, s);
+    return launch_tile_as<CA, COUT, NT, MS, WD, NP, float>(a, s);
 }
 
 }  // namespace
@@ -175,20 +186,20 @@ bool launch_tile(const ConvArgs &a, hipStream_t s)
 // true: launched.  false: shape not covered (the caller falls back to the per-layer kernel).
 bool launch_conv_tile_bf16(const ConvArgs &a, hipStream_t s)
 {
-    if (a.mode == CONV_UPCAT && a.gn_ab && a.io_bf16 && !a.silu && a.out_f32 && !a.scale && a.W <= 32 && a.W >= 4 && a.H >= 1 &&
+    if (a.mode == CONV_UPCAT && a.gn_ab && a.io_f16 && !a.silu && a.out_f32 && !a.scale && a.W <= 32 && a.W >= 4 && a.H >= 1 &&
         a.C0 % 8 == 0 && (a.C0 == 0 || !((a.W | a.H) & 1))) {
         // (C0 = 0: a plain tensor in in1)
         const int ci = a.C0 + a.C1, co = a.Cout;
-        if (ci == 32 && co == 32) return launch_tile_as<32, 32, 3, 1, 2, 14, __bf16, true>(a, s);
-        if (ci == 32 && co == 64) return launch_tile_as<32, 64, 2, 2, 2, 14, __bf16, true>(a, s);
-        if (ci == 64 && co == 64) return launch_tile_as<64, 64, 2, 2, 2, 14, __bf16, true>(a, s);
-        if (ci == 64 && co == 128) return launch_tile_as<64, 128, 2, 2, 2, 14, __bf16, true>(a, s);
-        if (ci == 128 && co == 128) return launch_tile_as<128, 128, 2, 2, 2, 14, __bf16, true>(a, s);
-        if (ci == 192 && co == 64) return launch_tile_as<192, 64, 2, 2, 2, 24, __bf16, true>(a, s);
-        if (ci == 96 && co == 32) return launch_tile_as<96, 32, 3, 1, 2, 24, __bf16, true>(a, s);
+        if (ci == 32 && co == 32) return launch_tile_as<32, 32, 3, 1, 2, 14, act16, true>(a, s);
+        if (ci == 32 && co == 64) return launch_tile_as<32, 64, 2, 2, 2, 14, act16, true>(a, s);
+        if (ci == 64 && co == 64) return launch_tile_as<64, 64, 2, 2, 2, 14, act16, true>(a, s);
+        if (ci == 64 && co == 128) return launch_tile_as<64, 128, 2, 2, 2, 14, act16, true>(a, s);
+        if (ci == 128 && co == 128) return launch_tile_as<128, 128, 2, 2, 2, 14, act16, true>(a, s);
+        if (ci == 192 && co == 64) return launch_tile_as<192, 64, 2, 2, 2, 24, act16, true>(a, s);
+        if (ci == 96 && co == 32) return launch_tile_as<96, 32, 3, 1, 2, 24, act16, true>(a, s);
         return false;
     }
-    if (a.gn_ab) return false;
+    if (a.gn_ab || a.io_f16) return false;
     if (a.mode != CONV_PLAIN || a.C1 != 0 || a.silu || !a.out_f32 || a.scale || a.W > 32 || a.W < 4 || a.H < 1) return false;
     const int ci = a.C0, co = a.Cout;
     if (ci == 32 && co == 32) return launch_tile<32, 32, 3, 1, 2, 14>(a, s);

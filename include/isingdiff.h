@@ -286,7 +286,9 @@ int idm_bitflip_destroy(idm_bitflip *m);
 
 /* IDM_FP32 (default): canonical float32 arithmetic, bit-exact against the CPU restatement.  IDM_BF16: the
  * 3x3 convolutions of the ResBlocks take bf16 operands (GroupNorm + swish output and weights rounded to
- * bf16) on bf16 MFMA with float32 accumulation; everything else stays float32. */
+ * bf16) on bf16 MFMA with float32 accumulation; all other arithmetic stays float32.  On shapes its fused
+ * kernels cover (maps 16 .. 32 wide, 28 x 28 among them) the tensors between kernels are stored as IEEE half
+ * (saturating at +-65504) and the GroupNorms are applied inside the convolutions. */
 int idm_bitflip_set_precision(idm_bitflip *m, int precision);
 
 /* The five per-block time vectors swish(Dense_i(temb)) (:173, :200-203) for one embedding row

@@ -156,3 +156,51 @@ def test_bf16_sampler_flips_like_float32(setup, fast):
     h1 = bitflip.diffusion_backward(x0[:5], fast, T, seed=3, return_trajectory=False).cpu().numpy()
     h2 = bitflip.diffusion_backward(x0[5:], fast, T, seed=3, first_global_index=5, return_trajectory=False).cpu().numpy()
     assert np.array_equal(w, np.concatenate([h1, h2]))
+
+
+def test_bf16_activation_storage_matches_float32_storage(setup, fast, tmp_path):
+    """The bf16 mode keeps its activations in IEEE half between kernels and folds both GroupNorms of a ResBlock into the
+    convolutions' tile staging wherever those kernels cover the shape ((28, 28) and (12, 20) here; (8, 40) is wider than a
+    tile row and runs on float32 activations either way).  ISINGDIFF_BITFLIP_ACT=f32 (read once per process, so a child
+    runs it) keeps float32 activations and the separate GroupNorm kernels.  Each must meet the mode's tolerance against the
+    float32 oracle with room to spare (half storage adds 1/64 of the bf16 operand rounding, not a second one), and the two
+    differ from one another by no more than two independent bf16 roundings of the same values can."""
+    import os, subprocess, sys
+    bitflip, model, ref = setup
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, 'diffusion-model_amd')\n"
+        "from isingdiff import bitflip\n"
+        "m = bitflip.BitflipModel(bitflip.synthetic_weights(0), device=0, time_step=100, precision='bf16')\n"
+        "out = {}\n"
+        "for H, W in ((28, 28), (12, 20)):\n"
+        "    x = (np.random.RandomState(11).rand(6, H, W, 1) < 0.5).astype(np.uint8)\n"
+        "    for t in (99, 0):\n"
+        "        p, taps = m([x, np.full(6, np.float32(t) / np.float32(100), np.float32)], taps=True)\n"
+        "        out[f'p_{H}_{t}'] = p.cpu().numpy()\n"
+        "        for i, a in enumerate(taps): out[f'tap{i}_{H}_{t}'] = a.cpu().numpy()\n"
+        "np.savez(sys.argv[1] + '/f32act.npz', **out)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, cwd=root,
+                   env=dict(os.environ, ISINGDIFF_BITFLIP_ACT="f32"), timeout=240)
+    other = np.load(tmp_path / "f32act.npz")
+    emb = bitflip.sinusoidal_table(100)
+    differs = False
+    for H, W in ((28, 28), (12, 20)):
+        x = (np.random.RandomState(11).rand(6, H, W, 1) < 0.5).astype(np.uint8)
+        for t in (99, 0):
+            p, taps = fast([x, np.full(6, np.float32(t) / np.float32(100), np.float32)], taps=True)
+            pr, tr = ref.forward(x[..., 0], emb[t], taps=True)
+            p = p.cpu().numpy()
+            assert np.max(np.abs(p - other[f"p_{H}_{t}"])) <= 1.5e-2
+            assert np.sqrt(np.mean((p - other[f"p_{H}_{t}"]) ** 2)) <= 4e-3
+            for q in (p, other[f"p_{H}_{t}"]):
+                assert np.max(np.abs(q[..., 0] - pr)) <= 0.75 * BF16_PROBA_ABS
+            for i, a in enumerate(taps):
+                a, o = a.cpu().numpy(), other[f"tap{i}_{H}_{t}"]
+                assert np.linalg.norm(a - o) <= 1e-2 * np.linalg.norm(o), f"ResBlock {i}, {H} x {W}, t={t}"
+                for q in (a, o):
+                    assert np.linalg.norm(q - tr[i]) <= 0.5 * BF16_TAP_REL_L2 * np.linalg.norm(tr[i])
+                differs |= not np.array_equal(a, o)
+    assert differs      # (the switch did select another set of kernels)
+

@@ -46,7 +46,7 @@ DEVI float rsqrt_canon(float v)
 // Activations between the kernels are float32 (parity mode; bf16 mode on shapes its fused kernels do not cover) or IEEE half
 // (bf16 mode otherwise: every tensor is rounded once where it is produced, all arithmetic stays float32).  Half, not bf16:
 // these tensors are rounded to bf16 again as convolution operands, and a bf16 store in between would double that rounding
-// noise (measured: 1.4 x the error against the float32 oracle); half's 11 bits add 1/64 of it.  Stores saturate at +-65504.
+// noise (measured: 1.4 x the error against float32 arithmetic); half's 11 bits add 1/64 of it.  Stores saturate at +-65504.
 DEVI f32x4 ld4(const float *p) { return *(const f32x4 *)p; }
 DEVI f32x4 ld4(const act16 *p)
 {

@@ -44,6 +44,11 @@ __global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__r
         cst[i] = bias[i];
         cst[COUT + i] = tadd ? tadd[i] : 0.0f;
     }
+    // (begin() only takes addresses and requests the first weight fragments: they arrive while the tile is staged)
+    using Conv = ConvStage<CA, 0, false, COUT, NT, MS, WD, true>;
+    Conv cs;
+    const LaneGeo geo = make_geo(W, lane & 31);
+    cs.begin(tile, nullptr, cst, cst + COUT, geo, 0, rows, w, wave, lane);
     if constexpr (GNUP) {
         constexpr int CH = CA / 8;
         const int Cu = gu.Cu, Cs = CA - Cu, Hh = H >> 1, Wh = W >> 1, ipr = W * CH, total = (rows + 2) * ipr;
@@ -107,10 +112,6 @@ __global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__r
         regs.load(in + (size_t)b * H * W * CA, H, W, y0 - 1, rows + 2, tid);
         regs.store(tile, W, rows + 2, tid);
     }
-    using Conv = ConvStage<CA, 0, false, COUT, NT, MS, WD, true>;
-    Conv cs;
-    const LaneGeo geo = make_geo(W, lane & 31);
-    cs.begin(tile, nullptr, cst, cst + COUT, geo, 0, rows, w, wave, lane);
     __syncthreads();
     OT *ob = out + ((size_t)b * H + y0) * W * COUT;
     // resid (same shape as out, may be null): added last, out = (conv + bias + vector) + resid - a ResBlock's identity shortcut

@@ -234,7 +234,8 @@ struct Plan {
     int R[5];            // band rows per fused kernel
     bool layers;         // bf16, 2-channel / BatchNorm model: layers 1..9 run as strip kernels (BatchNorm folded)
     bool tr;             // ... on the transposed map: H, W, Hp, Wp are then the transposed (processing) sizes
-    bool lpair[5];       // ... except these pairs (FK_M1, FK_M2, FK_M3), which run as fused band kernels with R[] rows
+    bool lpair[5];       // ... except these pairs (FK_M1, FK_M2, FK_M3; FK_B = conv8 + conv9 + the two-channel head, the kernel of
+                         // kind FK_BH2), which run as fused band kernels with R[] rows
     bool strip[5];       // this pair of layers runs as single-convolution strip kernels instead
     int sR[SK_COUNT], sWS[SK_COUNT];   // band rows / strip columns of the strip kernels
 };
@@ -349,6 +350,13 @@ Plan make_plan(const idm_model *m, int H, int W, int precision, bool allow_tr = 
             p.R[k] = pick_band_rows(k, hh[lv[k]], ww[lv[k]]);
             p.lpair[k] = p.R[k] > 0 && (p.R[k] >= 8 || p.R[k] >= hh[lv[k]]);
         }
+        // the last pair with the two-channel head (score only): 1 078 -> about 800 us per 16 384 spectra against the two strip
+        // launches (ISINGDIFF_SPECTRAL_BPAIR=0 keeps those; read once per process)
+        static const bool bpair = [] { const char *e = getenv("ISINGDIFF_SPECTRAL_BPAIR"); return !(e && e[0] == '0'); }();
+        if (m->C == 2 && bpair) {
+            p.R[FK_B] = pick_band_rows(FK_BH2, hh[0], ww[0]);
+            p.lpair[FK_B] = p.R[FK_B] >= 8;
+        }
         // Every layer needs its strip kernel (a caller that asks for the per-layer maps gets the strip launches) - except,
         // on the transposed map, where nobody can ask for them, the layers of a pair that runs fused and the stored conv9.
         const int pair_of[SK_COUNT] = {0, FK_M1, FK_M1, FK_M2, FK_M2, FK_M3, FK_M3, 0, 0, 0, 0};
@@ -358,7 +366,7 @@ Plan make_plan(const idm_model *m, int H, int W, int precision, bool allow_tr = 
             if (p.sR[sk] == 0 && !spared) p.layers = false;
         }
         if (!p.layers)
-            for (int k = FK_M1; k <= FK_M3; ++k) { p.R[k] = 0; p.lpair[k] = false; }
+            for (int k = FK_M1; k <= FK_B; ++k) { p.R[k] = 0; p.lpair[k] = false; }
     }
     if (p.tr && !p.layers) return make_plan(m, W, H, precision, false);   // (only the strip schedule has transposed weights)
     // Workspace: one buffer per kind, sized for what the selected schedule stores in it.  The fused schedule
@@ -700,7 +708,8 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
             a.tadd1 = l1 == 4 ? tadd : nullptr;
             if (p.tr) { a.w1_alt = m->wpack_tr_m16[l1]; a.w2_alt = m->wpack_tr_m16[l1 + 1]; }
             a.in_a = in_a; a.in_b = in_b; a.out = out; a.out_pool = out_pool;
-            a.H = H; a.W = W; a.R = p.R[kind]; a.nbands = (H + a.R - 1) / a.R;
+            if (kind == FK_BH2) { a.w_head = m->w_head; a.b_head = m->bias[10]; a.score_out = score; a.transpose_out = p.tr ? 1 : 0; }
+            a.H = H; a.W = W; a.R = p.R[kind == FK_BH2 ? FK_B : kind]; a.nbands = (H + a.R - 1) / a.R;
             a.Hx = p.H; a.Wx = p.W; a.B = Bc;
             fused_lds_bytes(kind, W, a.R, &a.lds_in_bytes, &a.lds_mid_bytes);
             char name[32];
@@ -730,9 +739,12 @@ int forward_chunk(idm_model *m, const Plan &p, const float *x, const float *tadd
             strip(SK_CONV6, 6, c5, s2, a6, nullptr, Hp / 2, Wp / 2);
             strip(SK_CONV7, 7, a6, nullptr, a7, nullptr, Hp / 2, Wp / 2);
         }
-        strip(SK_CONV8, 8, a7, s1, a8, nullptr, Hp, Wp);
-        if (fuse_head) strip(SK_CONV9H2, 9, a8, nullptr, nullptr, nullptr, Hp, Wp);
-        else strip(SK_CONV9S, 9, a8, nullptr, a9, nullptr, Hp, Wp);
+        if (fuse_head && p.lpair[FK_B]) pair(FK_BH2, 8, a7, s1, nullptr, nullptr, Hp, Wp);
+        else {
+            strip(SK_CONV8, 8, a7, s1, a8, nullptr, Hp, Wp);
+            if (fuse_head) strip(SK_CONV9H2, 9, a8, nullptr, nullptr, nullptr, Hp, Wp);
+            else strip(SK_CONV9S, 9, a8, nullptr, a9, nullptr, Hp, Wp);
+        }
         if (rc != IDM_OK) return rc;
         if (!fuse_head)
             timed(m, "head", 2.0 * F * m->C * Bc * p.H * p.W, (double)Bc * p.H * p.W * (F * 2 + m->C * 4), s,

@@ -33,7 +33,7 @@ constexpr bool BIAS_IN_ACC = true;
 #endif
 
 enum { M1_PLAIN = 0, M1_UPCAT = 1, M1_FIRST = 2 };
-enum { E2_STORE = 0, E2_STORE_POOL = 1, E2_HEAD = 2 };
+enum { E2_STORE = 0, E2_STORE_POOL = 1, E2_HEAD = 2, E2_HEAD2 = 3 };   // E2_HEAD2: 1x1 head with two output channels, score only
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 

@@ -199,24 +199,32 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
     char *lds_mid = smem + a.lds_in_bytes;
     char *tile_a = lds_in;
     char *tile_b = MODE1 == M1_UPCAT ? lds_in + ((((R >> 1) + 2) * ((W >> 1) + 2) * SA + 15) & ~15) : nullptr;
-    constexpr int NCONST = 2 * C1 + 2 * C2 + 4;
-    float *score_s = (float *)(smem + a.lds_in_bytes + a.lds_mid_bytes - (EPI2 == E2_HEAD ? (R * W * 4 + 15) & ~15 : 0));
+    // HEADX: a head follows the second convolution (E2_HEAD: one channel + the state update; E2_HEAD2: two channels, score
+    // only); its score tile, [R][W] floats or (Re, Im) pairs, lies behind the constants
+    constexpr bool HEADX = EPI2 == E2_HEAD || EPI2 == E2_HEAD2;
+    constexpr int NCONST = 2 * C1 + 2 * C2 + 4 + (EPI2 == E2_HEAD2 ? C2 : 0);
+    float *score_s = (float *)(smem + a.lds_in_bytes + a.lds_mid_bytes -
+                               (EPI2 == E2_HEAD ? (R * W * 4 + 15) & ~15 : EPI2 == E2_HEAD2 ? (R * W * 8 + 15) & ~15 : 0));
     float *cst = score_s - NCONST;
-    const float *c_b1 = cst, *c_t1 = cst + C1, *c_b2 = cst + 2 * C1, *c_wh = c_b2 + C2, *c_bh = c_b2 + 2 * C2;
-    (void)c_t1; (void)c_wh; (void)c_bh;
+    const float *c_b1 = cst, *c_t1 = cst + C1, *c_b2 = cst + 2 * C1, *c_wh = c_b2 + C2, *c_bh = c_b2 + 2 * C2, *c_wh2 = c_bh + 4;
+    (void)c_t1; (void)c_wh; (void)c_bh; (void)c_wh2;
     for (int i = tid; i < C1; i += WGS) {
         cst[i] = a.b1[i];
         cst[C1 + i] = TADD ? a.tadd1[i] : 0.0f;
     }
     for (int i = tid; i < C2; i += WGS) {
         cst[2 * C1 + i] = a.b2[i];
-        cst[2 * C1 + C2 + i] = EPI2 == E2_HEAD ? a.w_head[i] : 0.0f;
+        cst[2 * C1 + C2 + i] = EPI2 == E2_HEAD ? a.w_head[i] : EPI2 == E2_HEAD2 ? a.w_head[2 * i] : 0.0f;
+        if constexpr (EPI2 == E2_HEAD2) cst[2 * C1 + 2 * C2 + 4 + i] = a.w_head[2 * i + 1];
     }
-    if (tid == 0) cst[2 * C1 + 2 * C2] = EPI2 == E2_HEAD ? a.b_head[0] : 0.0f;
+    if (tid == 0) {
+        cst[2 * C1 + 2 * C2] = HEADX ? a.b_head[0] : 0.0f;
+        cst[2 * C1 + 2 * C2 + 1] = EPI2 == E2_HEAD2 ? a.b_head[1] : 0.0f;
+    }
 
     const LaneGeo geo = make_geo(W, lane & 31);
     using Conv1 = ConvStage<MODE1 == M1_FIRST ? 16 : CA, MODE1 == M1_UPCAT ? CB : 0, MODE1 == M1_UPCAT, C1, NT1, MS1, WD1, TADD>;
-    using Conv2 = ConvStage<C1, 0, false, C2, NT2, MS2, WD2, EPI2 == E2_HEAD>;
+    using Conv2 = ConvStage<C1, 0, false, C2, NT2, MS2, WD2, HEADX>;
     constexpr bool EARLY_PF = Conv2::FULL;  // conv2 never waits on vector memory: request the next band before it
     Conv1 cs1;
     Conv2 cs2;
@@ -264,8 +272,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
         } else if constexpr (MODE1 == M1_PLAIN) {
             ra.store(tile_a, W, R + 4, tid);
         } else {
-            ra.template store<EPI2 != E2_HEAD>(tile_a, W >> 1, (R >> 1) + 2, tid);
-            rb.template store<EPI2 != E2_HEAD>(tile_b, W, R + 4, tid);
+            ra.template store<!HEADX>(tile_a, W >> 1, (R >> 1) + 2, tid);
+            rb.template store<!HEADX>(tile_b, W, R + 4, tid);
         }
     };
 
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
     };
 
     clear_halo<C1, WGS>(lds_mid, W, R + 2, 0, 0, tid);  // halo columns of the mid tile: never written afterwards
-    if constexpr (EPI2 == E2_HEAD && MODE1 == M1_UPCAT) {
+    if constexpr (HEADX && MODE1 == M1_UPCAT) {
         clear_halo<CA, WGS>(tile_a, W >> 1, (R >> 1) + 2, 0, 0, tid);
         clear_halo<CB, WGS>(tile_b, W, R + 4, 0, 0, tid);
     }
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
         // (specialised instances: the map height is a multiple of the band height, so every band is full and conv2's
         // operand addressing is the same in every band; the HEAD kernel measures 2 % slower with that knowledge - fewer
         // registers and instructions, a worse interleaving with its co-resident workgroup - and keeps the general form)
-        const int rows2 = (WT && RT && EPI2 != E2_HEAD) ? R : min(R, H - y0);
+        const int rows2 = (WT && RT && !HEADX) ? R : min(R, H - y0);
         const int npix2 = rows2 * W;
         // the last iteration reloads its own band (discarded): an unconditional load keeps the prefetch
         // registers dead across the convolutions instead of loop-carried
@@ -515,6 +523,49 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
                     xg[e] = reverse_update(a.c1, xg[e], a.beta, sc, zz, a.sd, a.add_noise != 0);
                 }
             }
+        } else if constexpr (EPI2 == E2_HEAD2) {
+            // the two-channel 1x1 head of the spectral model: the score leaves as (Re, Im) pairs, cropped to the unpadded
+            // spectrum; the state update stays a kernel of its own
+            static_assert(C2 == 32 && MS2 == 1, "one cout slice");
+            auto epi2 = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *kw, int mt, int r, int x, bool valid) {
+                (void)mt;
+                float pa[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 k2 = *(const f32x4 *)(c_wh2 + 8 * g + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float z = silu1(BIAS_IN_ACC ? acc[4 * g + i] : acc[4 * g + i] + kb[g][i]);
+                        pa[i] += z * kw[g][i];
+                        pb[i] += z * k2[i];
+                    }
+                }
+                float sa = (pa[0] + pa[1]) + (pa[2] + pa[3]), sb = (pb[0] + pb[1]) + (pb[2] + pb[3]);
+                sa += __shfl_xor(sa, 32, 64);
+                sb += __shfl_xor(sb, 32, 64);
+                if (valid && h == 0) *(f32x2 *)(score_s + (r * W + x) * 2) = f32x2{sa + c_bh[0], sb + c_bh[1]};
+            };
+            cs2.run(epi2, TLHOOK(18));
+            conv1_begin(nxt);
+            if constexpr (!EARLY_PF) pf_load(nxt);
+            __syncthreads();
+            carry_rows();
+            const int rowsx = min(rows2, Hx - y0), colsx = min(W, Wx);
+            if (rowsx > 0 && colsx > 0 && !a.transpose_out) {
+                float *sg = a.score_out + (((int64_t)b * Hx + y0) * Wx) * 2;
+                for (int i = tid; i < rowsx * colsx; i += WGS) {
+                    const int r = i / colsx, xc = i - r * colsx;
+                    *(f32x2 *)(sg + ((int64_t)r * Wx + xc) * 2) = *(const f32x2 *)(score_s + (r * W + xc) * 2);
+                }
+            } else if (rowsx > 0 && colsx > 0) {
+                // the caller's tensor is (B, Wx, Hx, 2): element (row y0 + r, column xc) of this map is its (xc, y0 + r);
+                // consecutive threads walk r, which is contiguous there
+                float *sg = a.score_out + ((int64_t)b * Wx * Hx + y0) * 2;
+                for (int i = tid; i < rowsx * colsx; i += WGS) {
+                    const int xc = i / rowsx, r = i - xc * rowsx;
+                    *(f32x2 *)(sg + ((int64_t)xc * Hx + r) * 2) = *(const f32x2 *)(score_s + (r * W + xc) * 2);
+                }
+            }
         } else {
             char *stage = ALIAS ? lds_mid : lds_in;  // [rows2][W] positions of SO bytes
             auto epi2 = [&](const f32x16 &acc, const f32x4 *kb, const f32x4 *, int mt, int r, int x, bool valid) {
@@ -567,7 +618,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
             }
         }
         TL(7);
-        if constexpr (EPI2 != E2_HEAD) __syncthreads();  // staging consumed before the next band's input overwrites the region
+        if constexpr (!HEADX) __syncthreads();  // staging consumed before the next band's input overwrites the region
         TL(8);
         cur = following;
 #ifdef IDM_TIMELINE
@@ -592,7 +643,7 @@ namespace {
 #define IDM_M3_WAVES 4
 #endif
 struct KindInfo { int mode1, ca, cb, c1, c2, epi2, npa, npb, nw; };
-constexpr KindInfo kKinds[5] = {
+constexpr KindInfo kKinds[FK_COUNT] = {
     {M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, 3, 0, 4},    // FK_A : x -> conv0 -> conv1 -> skip1, pooled
     {M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, 5, 0, 4},   // FK_M1: pooled -> conv2 -> conv3 -> skip2, pooled
     {M1_PLAIN, 64, 0, 128, 128, E2_STORE, 3, 0, 4},      // FK_M2: pooled -> conv4 (+time) -> conv5
@@ -604,6 +655,7 @@ constexpr KindInfo kKinds[5] = {
 #else
     {M1_UPCAT, 64, 32, 32, 32, E2_HEAD, 3, 6, 4},     // FK_B with four wavefronts and 8-row bands
 #endif
+    {M1_UPCAT, 64, 32, 32, 32, E2_HEAD2, 3, 6, 4},    // FK_BH2: [up(conv7), skip1] -> conv8 -> conv9 -> two-channel head
 };
 
 inline int align16(int v) { return (v + 15) & ~15; }
@@ -642,10 +694,13 @@ void fused_lds_bytes(int kind, int W, int R, int *in_bytes, int *mid_bytes)
     if (k.mode1 == M1_FIRST) in = (R + 4) * (W + 2) * 4;
     else if (k.mode1 == M1_PLAIN) in = (R + 4) * (W + 2) * sa;
     else in = align16((R / 2 + 2) * (W / 2 + 2) * sa) + (R + 4) * (W + 2) * sb;
-    const int stage = k.epi2 == E2_HEAD ? 0 : R * W * so;
+    const bool headx = k.epi2 == E2_HEAD || k.epi2 == E2_HEAD2;
+    const int stage = headx ? 0 : R * W * so;
     *in_bytes = align16(in > stage ? in : stage);
-    // mid tile, then the epilogue constants (2*C1 + 2*C2 + 4 floats), then HEAD's score tile
-    *mid_bytes = align16((R + 2) * (W + 2) * sm) + (2 * k.c1 + 2 * k.c2 + 4) * 4 + (k.epi2 == E2_HEAD ? align16(R * W * 4) : 0);
+    // mid tile, then the epilogue constants (2*C1 + 2*C2 + 4 floats, C2 more for the second head channel), then the heads'
+    // score tile
+    *mid_bytes = align16((R + 2) * (W + 2) * sm) + (2 * k.c1 + 2 * k.c2 + 4 + (k.epi2 == E2_HEAD2 ? k.c2 : 0)) * 4 +
+                 (k.epi2 == E2_HEAD ? align16(R * W * 4) : k.epi2 == E2_HEAD2 ? align16(R * W * 8) : 0);
 }
 
 // conv2 + conv3 of the 32 x 32 lattice run on the whole 16 x 16 map (IDM_M1_WHOLE=0 at build time: 8-row bands).
@@ -721,10 +776,12 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
 
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
 {
-    static thread_local LaunchState all_st[IDM_MAX_DEVICES][11];   // one slot per kernel FUNCTION (attributes and occupancy are per function)
+    static thread_local LaunchState all_st[IDM_MAX_DEVICES][12];   // one slot per kernel FUNCTION (attributes and occupancy are per function)
     const int slot = idm_device_slot();
     if (slot < 0) return hipErrorInvalidDevice;
     LaunchState *st = all_st[slot];
+    if (kind == FK_BH2)
+        return launch_one(st[11], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD2, false, IDM_CFG_B, 0, 0, IDM_B_WAVES>, a, B, s, IDM_B_WAVES * 64);
     // instances specialised for the L = 32 pyramid (widths 32 / 16 / 8; 8-row bands, M3 the whole 16-row map; no padding)
     const int w32[5] = {32, 16, 8, 16, 32}, r32[5] = {8, 8, 8, 16, IDM_B_WAVES == 8 ? 16 : 8};
     const bool spec = a.W == w32[kind] && a.R == r32[kind] && a.Hx == 32 && a.Wx == 32;

@@ -107,7 +107,8 @@ void launch_conv_bf16(const ConvArgs &a, hipStream_t s);
 bool launch_conv_tile_bf16(const ConvArgs &a, hipStream_t s);
 
 // ---- fused two-convolution band kernels (idm_fused.hip) ----
-enum FusedKind { FK_A = 0, FK_M1 = 1, FK_M2 = 2, FK_M3 = 3, FK_B = 4 };
+// FK_BH2: FK_B's two convolutions followed by the two-channel head of the spectral model (score only, no update)
+enum FusedKind { FK_A = 0, FK_M1 = 1, FK_M2 = 2, FK_M3 = 3, FK_B = 4, FK_BH2 = 5, FK_COUNT = 6 };
 
 struct FusedArgs {
     int H, W;          // map size of this level (conv outputs)
@@ -128,7 +129,8 @@ struct FusedArgs {
     const float *w_head;
     const float *b_head;
     float *x;                // state, updated in place
-    float *score_out;        // optional (B,Hx,Wx)
+    float *score_out;        // optional (B,Hx,Wx); FK_BH2: (B,Hx,Wx,2), or (B,Wx,Hx,2) when transpose_out
+    int transpose_out;       // FK_BH2: the map is processed transposed, the score leaves in the caller's layout
     const float *noise;      // optional injected standard normals (B,Hx,Wx)
     float c1, beta, sd;
     int add_noise, do_update;

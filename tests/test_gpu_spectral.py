@@ -129,6 +129,36 @@ def test_first_layer_on_the_matrix_cores_matches_the_vector_alu_kernel(gpu_fft, 
         assert np.mean(t0 != w0) < 1e-2, tag   # (about one value in 300: sums with cancellation see the 2^-17 of the split)
 
 
+def test_last_pair_with_the_two_channel_head_fused_matches_the_strip_kernels(gpu_fft, tmp_path):
+    """conv8 + conv9 + the two-channel head of the bf16 schedule run as ONE band kernel (8-row bands of the top level, the
+    mid tile never leaves LDS); ISINGDIFF_SPECTRAL_BPAIR=0 (read once per process) keeps the two strip launches.  Same
+    weights, same operand order, same epilogue expressions: the scores must be identical bit for bit - on the transposed
+    map (L = 32: 20 rows, bands of 8 + 8 + 4, the score cropped to 17 rows and written back transposed), on the plain one
+    (L = 20: 20 x 12 map) and for a batch that leaves workgroups without work."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.join(root, 'diffusion-model_amd')!r})\n"
+        "from isingdiff.keras_file import load_unet_spec\n"
+        "from isingdiff.model import ScoreModel\n"
+        f"m = ScoreModel(load_unet_spec({os.path.join(root, 'weights', 'b_diffusion_model_2d_ising_unet.keras')!r}), device=0, precision='fp32')\n"
+        "for tag in ('a', 'b', 'c'):\n"
+        "    x = np.load(os.path.join(sys.argv[1], f'x{tag}.npy'))\n"
+        "    np.save(os.path.join(sys.argv[1], f's{tag}.npy'), np.asarray(m([x, np.float32(0.3)], precision='bf16')))\n")
+    xs = {"a": spectra(np.random.default_rng(80), 3, 32, 300), "b": spectra(np.random.default_rng(81), 5, 20, 300),
+          "c": spectra(np.random.default_rng(82), 700, 32, 300)}
+    for tag, x in xs.items():
+        np.save(tmp_path / f"x{tag}.npy", x)
+    assert "ISINGDIFF_SPECTRAL_BPAIR" not in os.environ
+    subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, env=dict(os.environ, ISINGDIFF_SPECTRAL_BPAIR="0"), timeout=240)
+    for tag, x in xs.items():
+        got = np.asarray(gpu_fft([x, np.float32(0.3)], precision="bf16"))
+        want = np.load(tmp_path / f"s{tag}.npy")
+        assert np.isfinite(got).all() and got.shape == want.shape
+        assert np.array_equal(got, want), (tag, rel_l2(got, want))
+
+
 def test_fft_unet_sampler_fp32_bit_exact(gpu_fft, ref_fft):
     """Full 1000-step schedule on the 2-channel spectral state with injected noise (this variant's
     dynamics is stable, std(x) stays O(10)), then irfft2 + sign against numpy."""

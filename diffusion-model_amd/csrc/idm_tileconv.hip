@@ -20,6 +20,17 @@ typedef _Float16 act16;
 typedef __attribute__((ext_vector_type(4))) _Float16 a16x4;
 typedef __attribute__((ext_vector_type(8))) _Float16 a16x8;
 
+#ifdef IDM_TC_TIMELINE   // timing build: clock stamps of wavefronts 0 and 3 of 64 mid-launch workgroups of the 96 -> 32 instance
+__device__ long long g_tc[64][2][16];
+#define TCS(i)                                                                                                  \
+    do {                                                                                                        \
+        if (CA == 96 && GNUP && lane == 0 && (wave == 0 || wave == 3) && blockIdx.x >= 4096 && blockIdx.x < 4160) \
+            g_tc[blockIdx.x - 4096][wave == 3][i] = (i) == 15 ? (long long)wall_clock64() : (long long)clock64();  \
+    } while (0)
+#else
+#define TCS(i) do { } while (0)
+#endif
+
 struct GnUpSrc {
     const act16 *skip;    // (B, H, W, CA - Cu); the kernel's `in` is up, (B, H / 2, W / 2, Cu)
     const float *ab;      // (B, CA, 2)
@@ -27,7 +38,7 @@ struct GnUpSrc {
 };
 
 template <int CA, int COUT, int NT, int MS, int WD, int NP, typename OT, bool GNUP = false>
-__global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__restrict__ in, const bf16x8 *__restrict__ w,
+__global__ __launch_bounds__(256, 2) void tile_conv_f32out_kernel(const __bf16 *__restrict__ in, const bf16x8 *__restrict__ w,
                                                               const float *__restrict__ bias, const float *__restrict__ tadd,
                                                               const OT *__restrict__ resid, OT *__restrict__ out, int H,
                                                               int W, int R, int nbands, GnUpSrc gu)
@@ -39,6 +50,8 @@ __global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__r
     const int y0 = (int)(blockIdx.x % nbands) * R;
     const int rows = min(R, H - y0);
     char *tile = smem;
+    TCS(0);
+    TCS(15);
     float *cst = (float *)(smem + (((R + 2) * (W + 2) * SA + 15) & ~15));
     for (int i = tid; i < COUT; i += 256) {
         cst[i] = bias[i];
@@ -49,70 +62,87 @@ __global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__r
     Conv cs;
     const LaneGeo geo = make_geo(W, lane & 31);
     cs.begin(tile, nullptr, cst, cst + COUT, geo, 0, rows, w, wave, lane);
+    TCS(1);
     if constexpr (GNUP) {
-        constexpr int CH = CA / 8;
-        const int Cu = gu.Cu, Cs = CA - Cu, Hh = H >> 1, Wh = W >> 1, ipr = W * CH, total = (rows + 2) * ipr;
-        const act16 *ub = (const act16 *)in + (size_t)b * Hh * Wh * Cu, *sb = gu.skip + (size_t)b * H * W * Cs;
+        // Items (tile pixel, eight channels).  A thread keeps ONE channel octet (tid % CH; 256 / CH pixels per step, the
+        // 256 % CH last threads idle), so the (a, b) pairs of its channels sit in registers for all its pixels and whether it
+        // reads up or skip is fixed: no table in LDS (clock stamps of the first version: four dependent LDS reads per item
+        // cost about 1 000 cycles per item, 16 k of a workgroup's 39 k), no per-item channel arithmetic.  The pixel
+        // (tile row t, column xc) is stepped from one item to the next.  Rounds of U items, software-pipelined: round r + 1's
+        // loads are issued before round r is processed, so only the first round's latency is exposed (all NP at once would
+        // cost the 24-item instances their second workgroup per CU).
+        constexpr int CH = CA / 8, PPS = 256 / CH, U = 8, NR = (NP + U - 1) / U;
+        const int Cu = gu.Cu, Cs = CA - Cu, Hh = H >> 1, Wh = W >> 1;
+        const int ch = tid % CH, q0 = tid / CH;
+        const bool act = q0 < PPS, from_up = 8 * ch < Cu;
+        const act16 *ub = (const act16 *)in + (size_t)b * Hh * Wh * Cu + 8 * ch, *sb = gu.skip + (size_t)b * H * W * Cs + (8 * ch - Cu);
+        f32x4 kab[4];   // (a, b) of channels 8 ch + 2 j, 8 ch + 2 j + 1
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kab[j] = *(const f32x4 *)(gu.ab + (size_t)b * 2 * CA + 16 * ch + 4 * j);
         bf16x8 zero;
         a16x8 zraw;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { zero[j] = (__bf16)0.0f; zraw[j] = (act16)0.0f; }
-        // items (tile row, column, eight channels), in rounds of U per thread: a round's loads are all in flight before its
-        // first item is used (all NP at once would cost the 24-item instances their second workgroup per CU)
-        constexpr int U = 8;
-        auto item = [&](int i, int &t, int &xc, int &ch) {
-            t = i / ipr;
-            const int rem = i - t * ipr;
-            xc = rem / CH;
-            ch = rem - xc * CH;
+        const int dt = PPS / W, dx = PPS - dt * W;
+        auto step = [&](int &t, int &xc) {
+            t += dt;
+            xc += dx;
+            if (xc >= W) { xc -= W; ++t; }
         };
-        float *abt = cst + 2 * COUT;
-        for (int i = tid; i < 2 * CA; i += 256) abt[i] = gu.ab[(size_t)b * 2 * CA + i];
-        bool synced = false;
-#pragma unroll
-        for (int k0 = 0; k0 < NP; k0 += U) {
-            a16x8 raw[U];
+        int tl = q0 / W, xl = q0 - tl * W;   // the next pixel to load
+        int tp = tl, xp = xl;                 // the next pixel to process
+        a16x8 raw[2][U];
+        auto issue = [&](auto RR) {
+            constexpr int r = decltype(RR)::value;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int i = tid + (k0 + u) * 256;
-                int t, xc, ch;
-                item(i, t, xc, ch);
-                const int gy = y0 - 1 + t;
-                const bool live = k0 + u < NP && i < total && gy >= 0 && gy < H;
-                const act16 *src = 8 * ch < Cu ? ub + (size_t)((gy >> 1) * Wh + (xc >> 1)) * Cu + 8 * ch
-                                               : sb + (size_t)(gy * W + xc) * Cs + (8 * ch - Cu);
-                raw[u] = live ? *(const a16x8 *)src : zraw;
+                if (r * U + u < NP) {
+                    const int gy = y0 - 1 + tl;
+                    const bool live = act && tl < rows + 2 && gy >= 0 && gy < H;
+                    const act16 *src = from_up ? ub + (size_t)((gy >> 1) * Wh + (xl >> 1)) * Cu : sb + (size_t)(gy * W + xl) * Cs;
+                    raw[r & 1][u] = live ? *(const a16x8 *)src : zraw;
+                    step(tl, xl);
+                }
             }
-            if (!synced) { __syncthreads(); synced = true; }   // the (a, b) table
+        };
+        auto process = [&](auto RR) {
+            constexpr int r = decltype(RR)::value;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int i = tid + (k0 + u) * 256;
-                if (k0 + u >= NP || i >= total) break;
-                int t, xc, ch;
-                item(i, t, xc, ch);
-                const int gy = y0 - 1 + t;
-                bf16x8 o = zero;
-                if (gy >= 0 && gy < H) {
-                    const float *abp = abt + 16 * ch;
+                if (r * U + u < NP) {
+                    const int gy = y0 - 1 + tp;
+                    const bool inside = gy >= 0 && gy < H;
+                    bf16x8 o;
 #pragma unroll
                     for (int j = 0; j < 8; j += 2) {
-                        const f32x4 kk = *(const f32x4 *)(abp + 2 * j);   // a, b of channels j and j + 1
-                        const float z0 = __builtin_fmaf((float)raw[u][j], kk[0], kk[1]),
-                                    z1 = __builtin_fmaf((float)raw[u][j + 1], kk[2], kk[3]);
+                        const f32x4 kk = kab[j >> 1];
+                        const float z0 = __builtin_fmaf((float)raw[r & 1][u][j], kk[0], kk[1]),
+                                    z1 = __builtin_fmaf((float)raw[r & 1][u][j + 1], kk[2], kk[3]);
                         o[j] = (__bf16)(z0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z0 * -1.4426950408889634f)));
                         o[j + 1] = (__bf16)(z1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z1 * -1.4426950408889634f)));
                     }
+                    if (act && tp < rows + 2) *(bf16x8 *)(tile + (tp * (W + 2) + xp + 1) * SA + ch * 16) = inside ? o : zero;
+                    step(tp, xp);
                 }
-                *(bf16x8 *)(tile + (t * (W + 2) + xc + 1) * SA + ch * 16) = o;
             }
-        }
+        };
+        issue(std::integral_constant<int, 0>{});
+        TCS(2);
+        static_for<0, NR>([&](auto RR) {
+            constexpr int r = decltype(RR)::value;
+            if constexpr (r + 1 < NR) issue(std::integral_constant<int, r + 1>{});
+            process(RR);
+            TCS(3 + 2 * r);
+        });
         clear_halo<CA, 256>(tile, W, rows + 2, 0, 0, tid);
+        TCS(8);
     } else {
         TileRegs<CA, NP, 256> regs;
         regs.load(in + (size_t)b * H * W * CA, H, W, y0 - 1, rows + 2, tid);
         regs.store(tile, W, rows + 2, tid);
     }
     __syncthreads();
+    TCS(9);
     OT *ob = out + ((size_t)b * H + y0) * W * COUT;
     // resid (same shape as out, may be null): added last, out = (conv + bias + vector) + resid - a ResBlock's identity shortcut
     const OT *rb = resid ? resid + ((size_t)b * H + y0) * W * COUT : nullptr;
@@ -137,7 +167,12 @@ __global__ __launch_bounds__(256) void tile_conv_f32out_kernel(const __bf16 *__r
                 *(a16x4 *)(ob + o + 8 * g) = o4;
             }
         }
-    });
+    }, [&](int i) { if (i == 0) TCS(10); if (i == 1) TCS(11); if (i == 2) TCS(12); });
+    TCS(13);
+#ifdef IDM_TC_TIMELINE
+    __builtin_amdgcn_s_waitcnt(0);
+    TCS(14);
+#endif
 }
 
 template <int CA, int COUT, int NT, int MS, int WD, int NP, typename OT, bool GNUP = false>
@@ -151,8 +186,9 @@ bool launch_tile_as(const ConvArgs &a, hipStream_t s)
     // measured no faster: 52 KB +0.3 %, 39 KB -2.6 %, 30 KB -13 % for the bit-flip sampler)
     constexpr int budget = 76 * 1024;
     auto fits = [&](int r) {
-        return (int64_t)(r + 2) * a.W * (CA / 8) <= (int64_t)NP * 256 &&
-               (r + 2) * (a.W + 2) * SA + 2 * COUT * 4 + (GNUP ? 2 * CA * 4 : 0) + 16 <= budget;
+        // (GNUP: a thread stages one channel octet of 256 / (CA / 8) pixels per step)
+        return (GNUP ? (int64_t)(r + 2) * a.W <= (int64_t)NP * (256 / (CA / 8)) : (int64_t)(r + 2) * a.W * (CA / 8) <= (int64_t)NP * 256) &&
+               (r + 2) * (a.W + 2) * SA + 2 * COUT * 4 + 16 <= budget;
     };
     while (!fits(R)) {
         if (R == 1) return false;
@@ -161,7 +197,7 @@ bool launch_tile_as(const ConvArgs &a, hipStream_t s)
     }
     nb = (a.H + R - 1) / R;
     if (a.B * nb > 0x7fffffff) return false;
-    const int lds = (((R + 2) * (a.W + 2) * SA + 15) & ~15) + 2 * COUT * 4 + (GNUP ? 2 * CA * 4 : 0);
+    const int lds = (((R + 2) * (a.W + 2) * SA + 15) & ~15) + 2 * COUT * 4;
     auto kernel = tile_conv_f32out_kernel<CA, COUT, NT, MS, WD, NP, OT, GNUP>;
     static thread_local bool configured[IDM_MAX_DEVICES] = {};
     const int slot = idm_device_slot();
@@ -183,6 +219,10 @@ bool launch_tile(const ConvArgs &a, hipStream_t s)
 }
 
 }  // namespace
+
+#ifdef IDM_TC_TIMELINE
+extern "C" int idm_tc_timeline(long long *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tc), sizeof(g_tc)); }
+#endif
 
 // true: launched.  false: shape not covered (the caller falls back to the per-layer kernel).
 bool launch_conv_tile_bf16(const ConvArgs &a, hipStream_t s)

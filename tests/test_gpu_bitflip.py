@@ -117,10 +117,12 @@ def fast(setup):
     return bitflip.BitflipModel(model.weights, device=0, time_step=100, precision="bf16")
 
 
-@pytest.mark.parametrize("hw", [(28, 28), (12, 20), (8, 40)])
+@pytest.mark.parametrize("hw", [(28, 28), (12, 20), (8, 40), (32, 32), (4, 16), (64, 24)])
 def test_bf16_forward_within_tolerance(setup, fast, hw):
-    """(28, 28) and (12, 20): LDS-tiled convolutions, whole maps and bands; (8, 40): wider than a 32-pixel tile row, the
-    per-layer convolution kernel.  GroupNorm + swish in one workgroup per sample and the MFMA shortcuts in all three."""
+    """(28, 28) and (12, 20): LDS-tiled convolutions, whole maps and bands, half activations with the GroupNorms folded into
+    the staging; (8, 40): wider than a 32-pixel tile row, the per-layer convolution kernel on float32 activations with
+    one-workgroup GroupNorm + swish kernels.  (32, 32): the widest tile row; (4, 16): one-row maps at the third level;
+    (64, 24): several bands per map at every level.  MFMA shortcuts in all of them."""
     bitflip, model, ref = setup
     H, W = hw
     rs = np.random.RandomState(6)

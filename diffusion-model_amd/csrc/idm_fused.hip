@@ -148,7 +148,8 @@ extern "C" int idm_debug_timeline2(long long *host, unsigned *hw)
 // OCC: wavefronts per SIMD the register budget is sized for (= workgroups per CU when LDS allows).
 // WT, RT: map width and band rows as compile-time constants (0 = taken from the arguments); the
 // specialised instances turn the index arithmetic of the tile copies into shifts and immediates.
-template <int MODE1, int CA, int CB, int C1, int C2, int EPI2, bool TADD, int NT1, int MS1, int WD1, int NT2, int MS2, int WD2, int NPA, int NPB, int OCC, int WT, int RT, int NW = 4>
+// NBC: the map is WT x WT, so the number of bands is the constant WT / RT (false: rectangular maps, a.nbands).
+template <int MODE1, int CA, int CB, int C1, int C2, int EPI2, bool TADD, int NT1, int MS1, int WD1, int NT2, int MS2, int WD2, int NPA, int NPB, int OCC, int WT, int RT, int NW = 4, bool NBC = true>
 __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -158,7 +159,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
     const int wave = tid >> 6;
     const int h = lane >> 5;
     const int W = WT ? WT : a.W, H = a.H, R = RT ? RT : a.R;
-    const int Hx = WT ? 32 : a.Hx, Wx = WT ? 32 : a.Wx;   // specialised instances: the L = 32 lattice
+    // specialised instances: the L = 32 pyramid, whose state is 32 x 32 - or, for the first pair alone (WT = 64 / 128), the
+    // square lattice of the map's own size
+    constexpr int XT = (MODE1 == M1_FIRST && WT > 32) ? WT : 32;
+    const int Hx = (WT && EPI2 != E2_HEAD2) ? XT : a.Hx, Wx = (WT && EPI2 != E2_HEAD2) ? XT : a.Wx;   // (the spectrum: its own size)
     (void)Hx; (void)Wx;
     constexpr int SA = CA * 2 + 16, SB = CB * 2 + 16, SM = C1 * 2 + 16, SO = C2 * 2 + 16;
     constexpr int CAT = MODE1 == M1_FIRST ? 8 : CA, CBT = MODE1 == M1_UPCAT ? CB : 8;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void fused2_kernel(FusedArgs a)
     // to bottom: item n of a workgroup is band n % nbands of its (n / nbands)-th lattice.  The two bottom rows of
     // the mid tile (conv1 at global rows y0+R-1, y0+R) are what the next band needs as its rows 0 and 1, so they
     // are carried over in LDS and conv1 never computes a row twice.  Specialised instances know nbands.
-    const int nbands = (WT && RT) ? WT / RT : a.nbands;
+    const int nbands = (WT && RT && NBC) ? WT / RT : a.nbands;
     const int nlat = (int)a.B;
     struct Item { int b, y0; };
     auto item_of = [&](int n) {
@@ -776,12 +780,37 @@ static hipError_t launch_one(LaunchState &st, K kernel, const FusedArgs &a, int6
 
 hipError_t launch_fused(int kind, const FusedArgs &a, int64_t B, hipStream_t s)
 {
-    static thread_local LaunchState all_st[IDM_MAX_DEVICES][12];   // one slot per kernel FUNCTION (attributes and occupancy are per function)
+    static thread_local LaunchState all_st[IDM_MAX_DEVICES][18];   // one slot per kernel FUNCTION (attributes and occupancy are per function)
     const int slot = idm_device_slot();
     if (slot < 0) return hipErrorInvalidDevice;
     LaunchState *st = all_st[slot];
-    if (kind == FK_BH2)
+    // (ISINGDIFF_FUSED_SHAPED=0, read once per process, keeps the run-time-shaped instances: identical results)
+    static const bool shaped = [] { const char *e = getenv("ISINGDIFF_FUSED_SHAPED"); return !(e && e[0] == '0'); }();
+    if (kind == FK_BH2) {
+        // (the transposed spectral map at L = 32: 32 columns, 8-row bands)
+        if (shaped && a.W == 32 && a.R == 8)
+            return launch_one(st[15], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD2, false, IDM_CFG_B, 32, 8, IDM_B_WAVES, false>, a, B, s, IDM_B_WAVES * 64);
         return launch_one(st[11], fused2_kernel<M1_UPCAT, 64, 32, 32, 32, E2_HEAD2, false, IDM_CFG_B, 0, 0, IDM_B_WAVES>, a, B, s, IDM_B_WAVES * 64);
+    }
+    // the second level of that map (10 rows x 16 columns, one band): conv2 + conv3 and conv6 + conv7
+    if (shaped && a.W == 16 && a.H == 10 && a.R == 10) {
+        if (kind == FK_M1)
+            return launch_one(st[16], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1, 16, 10, 4, false>, a, B, s);
+        if (kind == FK_M3)
+            return launch_one(st[17], fused2_kernel<M1_UPCAT, 128, 64, 64, 64, E2_STORE, false, IDM_CFG_M3, 16, 10, IDM_M3_WAVES, false>, a, B, s, IDM_M3_WAVES * 64);
+    }
+    // conv0 + conv1 of the L = 64 / 128 lattices in the bands the plan picks for them (4 / 2 rows): the same kernel with the
+    // map size known at compile time (the run-time-shaped instance spends 20 vector instructions per MFMA, 40 % more than
+    // the L = 32 one, on index arithmetic: it is bound by them)
+    if (shaped && kind == FK_A && a.H == a.W && a.Hx == a.W && a.Wx == a.W) {
+        if (a.W == 64 && a.R == 4)
+            return launch_one(st[12], fused2_kernel<M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, false, IDM_CFG_A, 64, 4>, a, B, s);
+        if (a.W == 128 && a.R == 2)
+            return launch_one(st[13], fused2_kernel<M1_FIRST, 1, 0, 32, 32, E2_STORE_POOL, false, IDM_CFG_A, 128, 2>, a, B, s);
+    }
+    // ... and conv2 + conv3 of the L = 64 lattice (32 x 32 maps in 4-row bands) likewise
+    if (shaped && kind == FK_M1 && a.W == 32 && a.H == 32 && a.R == 4)
+        return launch_one(st[14], fused2_kernel<M1_PLAIN, 32, 0, 64, 64, E2_STORE_POOL, false, IDM_CFG_M1, 32, 4>, a, B, s);
     // instances specialised for the L = 32 pyramid (widths 32 / 16 / 8; 8-row bands, M3 the whole 16-row map; no padding)
     const int w32[5] = {32, 16, 8, 16, 32}, r32[5] = {8, 8, 8, 16, IDM_B_WAVES == 8 ? 16 : 8};
     const bool spec = a.W == w32[kind] && a.R == r32[kind] && a.Hx == 32 && a.Wx == 32;

@@ -732,3 +732,35 @@ def test_conv4_conv5_whole_map_kernel_at_L64_matches_the_strips(gpu_real, real_s
         assert rel_l2(got_s, want_s.cpu().numpy()) < 1e-2, B
         if B == 1:
             assert rel_l2(want_s.cpu().numpy(), ref_real.forward(xs[B], np.float32(0.6))) < BF16_SCORE_TOL
+
+
+def test_shaped_first_pairs_at_L64_and_L128_are_bit_identical_to_the_run_time_shaped_kernels(gpu_real, tmp_path):
+    """conv0 + conv1 at L = 64 / 128 and conv2 + conv3 at L = 64 run on instances of the fused band kernel that know the map
+    and band size at compile time (16 - 17 % faster: the run-time-shaped instances are bound by their index arithmetic);
+    ISINGDIFF_FUSED_SHAPED=0 (read once per process) keeps the run-time-shaped ones.  Same arithmetic in the same order: the
+    scores and the skip maps must be identical bit for bit, for one lattice and for more lattices than workgroups."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {os.path.join(root, 'diffusion-model_amd')!r})\n"
+        "from isingdiff import load_model\n"
+        f"m = load_model({os.path.join(root, 'weights', 'b_diffusion_model_2d_ising_realspace_unet.keras')!r}, device=0, precision='bf16')\n"
+        "for tag in ('a', 'b', 'c'):\n"
+        "    x = np.load(os.path.join(sys.argv[1], f'x{tag}.npy'))\n"
+        "    s, taps = m.forward_taps(x, np.float32(0.4), precision='bf16')\n"
+        "    np.save(os.path.join(sys.argv[1], f's{tag}.npy'), s.cpu().numpy())\n"
+        "    np.save(os.path.join(sys.argv[1], f't1{tag}.npy'), taps[1].cpu().numpy())\n"
+        "    np.save(os.path.join(sys.argv[1], f't3{tag}.npy'), taps[3].cpu().numpy())\n")
+    rng = np.random.default_rng(90)
+    xs = {"a": ising_like(rng, 1, 64, 64, 400), "b": ising_like(rng, 600, 64, 64, 400), "c": ising_like(rng, 3, 128, 128, 400)}
+    for tag, x in xs.items():
+        np.save(tmp_path / f"x{tag}.npy", x)
+    assert "ISINGDIFF_FUSED_SHAPED" not in os.environ
+    subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, env=dict(os.environ, ISINGDIFF_FUSED_SHAPED="0"), timeout=240)
+    for tag, x in xs.items():
+        s, taps = gpu_real.forward_taps(x, np.float32(0.4), precision="bf16")
+        assert np.isfinite(s.cpu().numpy()).all()
+        assert np.array_equal(s.cpu().numpy(), np.load(tmp_path / f"s{tag}.npy")), tag
+        assert np.array_equal(taps[1].cpu().numpy(), np.load(tmp_path / f"t1{tag}.npy")), tag
+        assert np.array_equal(taps[3].cpu().numpy(), np.load(tmp_path / f"t3{tag}.npy")), tag

@@ -159,6 +159,33 @@ def test_last_pair_with_the_two_channel_head_fused_matches_the_strip_kernels(gpu
         assert np.array_equal(got, want), (tag, rel_l2(got, want))
 
 
+def test_shaped_band_kernels_of_the_transposed_map_are_bit_identical_to_the_run_time_shaped_ones(gpu_fft, tmp_path):
+    """At L = 32 the fused pairs of the transposed spectral map (conv2 + conv3 and conv6 + conv7 on 10 x 16, conv8 + conv9 +
+    head on 20 x 32 in 8-row bands) run on instances of the band kernel that know map and band size at compile time (+5 %);
+    ISINGDIFF_FUSED_SHAPED=0 (read once per process) keeps the run-time-shaped ones.  Same arithmetic, same order: identical
+    scores, for a few spectra and for more spectra than workgroups."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.join(root, 'diffusion-model_amd')!r})\n"
+        "from isingdiff.keras_file import load_unet_spec\n"
+        "from isingdiff.model import ScoreModel\n"
+        f"m = ScoreModel(load_unet_spec({os.path.join(root, 'weights', 'b_diffusion_model_2d_ising_unet.keras')!r}), device=0, precision='fp32')\n"
+        "for tag in ('a', 'b'):\n"
+        "    x = np.load(os.path.join(sys.argv[1], f'x{tag}.npy'))\n"
+        "    np.save(os.path.join(sys.argv[1], f's{tag}.npy'), np.asarray(m([x, np.float32(0.5)], precision='bf16')))\n")
+    xs = {"a": spectra(np.random.default_rng(85), 3, 32, 500), "b": spectra(np.random.default_rng(86), 700, 32, 500)}
+    for tag, x in xs.items():
+        np.save(tmp_path / f"x{tag}.npy", x)
+    assert "ISINGDIFF_FUSED_SHAPED" not in os.environ
+    subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, env=dict(os.environ, ISINGDIFF_FUSED_SHAPED="0"), timeout=240)
+    for tag, x in xs.items():
+        got = np.asarray(gpu_fft([x, np.float32(0.5)], precision="bf16"))
+        want = np.load(tmp_path / f"s{tag}.npy")
+        assert np.isfinite(got).all() and np.array_equal(got, want), (tag, rel_l2(got, want))
+
+
 def test_fft_unet_sampler_fp32_bit_exact(gpu_fft, ref_fft):
     """Full 1000-step schedule on the 2-channel spectral state with injected noise (this variant's
     dynamics is stable, std(x) stays O(10)), then irfft2 + sign against numpy."""
